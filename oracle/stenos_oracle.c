@@ -1,0 +1,1119 @@
+/*
+ * stenos_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see stenos_oracle.h).
+ *
+ * Scalar restatement of the Stenos level-1 block codec, one byte at a time, written from the
+ * bit-stream specification.  Every function cites the reference location whose observable
+ * behaviour it restates (paths relative to the reference checkout).
+ */
+#include "stenos_oracle.h"
+
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SB_DEFAULT 131072u            /* STENOS_BLOCK_SIZE, stenos/stenos.h:57 */
+#define SB_MAX ((1u << 24) - 1u)      /* STENOS_MAX_BLOCK_BYTES, stenos/stenos.h:61 */
+#define MAX_BYTESOFTYPE (SB_MAX / 256) /* stenos/stenos.h:65 */
+
+int so_has_error(size_t r) { return r >= SO_LAST_ERROR_CODE; } /* block_compress.h:91-94 */
+
+/* stenos/stenos.h:37-42 */
+size_t so_bound(size_t bytes)
+{
+	const size_t min_sb = 65792;
+	size_t n = bytes / min_sb + (bytes % min_sb ? 1 : 0);
+	return 12 + (n == 0 ? 1 : n) * 4 + bytes;
+}
+
+/* stenos.cpp:71-76 and 157-164 (no time limit, no custom shift) */
+static size_t base_superblock(size_t block_size)
+{
+	if (block_size > SB_DEFAULT)
+		return block_size;
+	return (SB_DEFAULT / block_size) * block_size;
+}
+size_t so_superblock_size(size_t bytesoftype, size_t bytes, int level)
+{
+	size_t sb = base_superblock(bytesoftype * 256);
+	if (bytes > sb)
+		sb <<= (level ? (level - 1) / 2 : 0);
+	return sb;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * shuffle / unshuffle / delta
+ * ---------------------------------------------------------------------------------------- */
+
+/* shuffle-generic.h:33-74: dest[j*N + i] = src[i*T + j]; leftover bytes copied verbatim */
+void so_shuffle(size_t T, size_t bytes, const uint8_t* src, uint8_t* dst)
+{
+	size_t n = bytes / T, rem = bytes % T;
+	if (T == 1) { /* shuffle.cpp:82-103: memcpy */
+		memcpy(dst, src, bytes);
+		return;
+	}
+	for (size_t j = 0; j < T; ++j)
+		for (size_t i = 0; i < n; ++i)
+			dst[j * n + i] = src[i * T + j];
+	memcpy(dst + (bytes - rem), src + (bytes - rem), rem);
+}
+/* shuffle-generic.h:83-125 */
+void so_unshuffle(size_t T, size_t bytes, const uint8_t* src, uint8_t* dst)
+{
+	size_t n = bytes / T, rem = bytes % T;
+	if (T == 1) {
+		memcpy(dst, src, bytes);
+		return;
+	}
+	for (size_t i = 0; i < n; ++i)
+		for (size_t j = 0; j < T; ++j)
+			dst[i * T + j] = src[j * n + i];
+	memcpy(dst + (bytes - rem), src + (bytes - rem), rem);
+}
+
+/* delta.cpp:30-71: one stream up to 2048 bytes, else four quarter streams + tail */
+void so_delta(const uint8_t* src, uint8_t* dst, size_t bytes)
+{
+	if (bytes == 0)
+		return;
+	if (bytes <= 2048) {
+		dst[0] = src[0];
+		for (size_t i = 1; i < bytes; ++i)
+			dst[i] = (uint8_t)(src[i] - src[i - 1]);
+		return;
+	}
+	size_t q = bytes / 4;
+	for (int s = 0; s < 4; ++s) {
+		dst[s * q] = src[s * q];
+		for (size_t i = 1; i < q; ++i)
+			dst[s * q + i] = (uint8_t)(src[s * q + i] - src[s * q + i - 1]);
+	}
+	for (size_t i = 4 * q; i < bytes; ++i)
+		dst[i] = (uint8_t)(src[i] - src[i - 1]);
+}
+/* delta.cpp:230-268 */
+void so_delta_inv(const uint8_t* src, uint8_t* dst, size_t bytes)
+{
+	if (bytes == 0)
+		return;
+	if (bytes <= 2048) {
+		dst[0] = src[0];
+		for (size_t i = 1; i < bytes; ++i)
+			dst[i] = (uint8_t)(dst[i - 1] + src[i]);
+		return;
+	}
+	size_t q = bytes / 4;
+	for (int s = 0; s < 4; ++s) {
+		dst[s * q] = src[s * q];
+		for (size_t i = 1; i < q; ++i)
+			dst[s * q + i] = (uint8_t)(dst[s * q + i - 1] + src[s * q + i]);
+	}
+	for (size_t i = 4 * q; i < bytes; ++i)
+		dst[i] = (uint8_t)(dst[i - 1] + src[i]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * plane analysis
+ * ---------------------------------------------------------------------------------------- */
+
+static int popcnt16(unsigned v)
+{
+	int c = 0;
+	for (v &= 0xFFFFu; v; v &= v - 1)
+		++c;
+	return c;
+}
+
+/* bit_scan_reverse_8_2, block_compress.h:334-352: bits needed for an unsigned byte range,
+ * with 7 promoted to 8 */
+static int width_of(unsigned v)
+{
+	int b = 0;
+	while (v) {
+		++b;
+		v >>= 1;
+	}
+	return b >= 7 ? 8 : b;
+}
+
+/* find_pack_bits_params, block_compress.h:385-535 (row = 16 consecutive bytes of the plane) */
+void so_analyse_plane(const uint8_t p[256], int rle, so_plane_info* info)
+{
+	memset(info, 0, sizeof(*info));
+
+	int same = 1;
+	for (int i = 1; i < 256; ++i)
+		if (p[i] != p[0]) {
+			same = 0;
+			break;
+		}
+	if (same) { /* :396, 406, 415-418 */
+		info->type = SO_PLANE_SAME;
+		info->size = 1;
+		return;
+	}
+
+	unsigned total = 8; /* 8 bytes of row-header nibbles, :476 */
+	int bits_of[16];
+	int no_min[16]; /* rows that do not emit a min byte */
+
+	for (int r = 0; r < 16; ++r) {
+		const uint8_t* row = p + 16 * r;
+		uint8_t d[16];
+		int mn = 127, mx = -128, mnd = 127, mxd = -128;
+		for (int c = 0; c < 16; ++c) {
+			/* previous byte in plane order, 0 before the first byte (:399-401) */
+			uint8_t prev = (r == 0 && c == 0) ? 0 : p[16 * r + c - 1];
+			d[c] = (uint8_t)(row[c] - prev);
+			int v = (int8_t)row[c], dv = (int8_t)d[c]; /* signed compare, :407-411 */
+			if (v < mn) mn = v;
+			if (v > mx) mx = v;
+			if (dv < mnd) mnd = dv;
+			if (dv > mxd) mxd = dv;
+		}
+		int b0 = width_of((uint8_t)(mx - mn));
+		int b1 = width_of((uint8_t)(mxd - mnd));
+		if (b0 == 6)
+			b0 = 8; /* header 6 is reserved for delta-rle, :422 */
+		int bits = b0 < b1 ? b0 : b1;
+		int type0 = (b0 == bits); /* ties go to frame-of-reference, :426-427 */
+		info->mins[r] = (uint8_t)(type0 ? mn : mnd);
+		int cost = 2 * bits + (bits != 8); /* :433-435 */
+		int hdr = type0 ? (b0 == 8 ? 15 : b0) : 8 + b1; /* :499-501 */
+
+		if (rle) {
+			/* rle on bytes: bit c set when byte equals the previous byte, :268-275 */
+			unsigned m = 0, md = 0;
+			for (int c = 0; c < 16; ++c) {
+				uint8_t prev = (r == 0 && c == 0) ? 0 : p[16 * r + c - 1];
+				if (row[c] == prev)
+					m |= 1u << c;
+				/* rle on deltas, previous delta of the first column is 0, :248-255, 449-458 */
+				uint8_t pd = c == 0 ? 0 : d[c - 1];
+				if (d[c] == pd)
+					md |= 1u << c;
+			}
+			info->rle_mask[r] = (uint16_t)m;
+			info->drle_mask[r] = (uint16_t)md;
+			int c1 = 2 + 16 - popcnt16(m);
+			if (c1 < cost) { /* strictly smaller, :464-467 */
+				cost = c1;
+				hdr = 7;
+			}
+			int c2 = 2 + 16 - popcnt16(md);
+			if (c2 < cost) { /* :470-472 */
+				cost = c2;
+				hdr = 6;
+			}
+		}
+		info->hdr[r] = (uint8_t)hdr;
+		info->cost[r] = (uint8_t)cost;
+		bits_of[r] = bits;
+		no_min[r] = (hdr == 6 || hdr == 7 || bits == 8);
+		total += (unsigned)cost;
+	}
+	info->type = SO_PLANE_NORMAL;
+
+	if (rle) { /* mins rle, :478-490 */
+		int count8 = 0;
+		for (int r = 0; r < 16; ++r)
+			count8 += no_min[r];
+		unsigned mm = 0;
+		for (int r = 0; r < 16; ++r) {
+			uint8_t prev = r == 0 ? 0 : info->mins[r - 1];
+			if (info->mins[r] == prev)
+				mm |= 1u << r;
+		}
+		info->mins_mask = (uint16_t)mm;
+		unsigned mins_rle = 2u + 16u - (unsigned)popcnt16(mm);
+		if (mins_rle < 16u - (unsigned)count8) {
+			info->type = SO_PLANE_NORMAL_RLE;
+			total -= (16u - (unsigned)count8) - mins_rle;
+			for (int r = 0; r < 16; ++r)
+				if (!no_min[r])
+					info->cost[r] -= 1;
+		}
+	}
+	(void)bits_of;
+	info->size = (uint16_t)total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * plane serialisation
+ * ---------------------------------------------------------------------------------------- */
+
+/* write_16, block_compress.h:562-602: two halves of 8 values, LSB first, `bits` bytes each */
+static uint8_t* pack16(const uint8_t v[16], int bits, uint8_t* dst)
+{
+	for (int h = 0; h < 2; ++h) {
+		uint64_t acc = 0;
+		for (int k = 0; k < 8; ++k)
+			acc |= (uint64_t)v[8 * h + k] << (k * bits);
+		for (int b = 0; b < bits; ++b)
+			*dst++ = (uint8_t)(acc >> (8 * b));
+	}
+	return dst;
+}
+
+/* write_rle_single, block_compress.h:258-265: [mask LE16][bytes whose mask bit is 0] */
+static uint8_t* put_rle(unsigned mask, const uint8_t v[16], uint8_t* dst)
+{
+	*dst++ = (uint8_t)mask;
+	*dst++ = (uint8_t)(mask >> 8);
+	for (int c = 0; c < 16; ++c)
+		if (!((mask >> c) & 1))
+			*dst++ = v[c];
+	return dst;
+}
+
+/* one row payload, write_line_for_type / write_line / write_delta_rle, block_compress.h:649-684 */
+static uint8_t* put_row(const uint8_t p[256], int r, const so_plane_info* info, uint8_t* dst)
+{
+	const uint8_t* row = p + 16 * r;
+	uint8_t d[16], v[16];
+	for (int c = 0; c < 16; ++c) {
+		uint8_t prev = (r == 0 && c == 0) ? 0 : p[16 * r + c - 1];
+		d[c] = (uint8_t)(row[c] - prev);
+	}
+	int h = info->hdr[r];
+	if (h == 15) {
+		memcpy(dst, row, 16);
+		return dst + 16;
+	}
+	if (h == 7)
+		return put_rle(info->rle_mask[r], row, dst);
+	if (h == 6)
+		return put_rle(info->drle_mask[r], d, dst);
+	int bits = h & 7;
+	if (bits == 0)
+		return dst;
+	for (int c = 0; c < 16; ++c)
+		v[c] = (uint8_t)((h < 8 ? row[c] : d[c]) - info->mins[r]);
+	return pack16(v, bits, dst);
+}
+
+/* encode16x16_generic (block_compress.h:739-806) for lines == 16 and encode_lines (:686-737)
+ * for partial blocks (never NORMAL_RLE there) */
+static uint8_t* put_plane(const uint8_t p[256], const so_plane_info* info, int lines, uint8_t* dst)
+{
+	if (info->type == SO_PLANE_SAME) {
+		*dst++ = p[0];
+		return dst;
+	}
+	int nh = lines / 2 + (lines & 1);
+	for (int k = 0; k < nh; ++k) {
+		unsigned lo = info->hdr[2 * k], hi = (2 * k + 1 < lines) ? info->hdr[2 * k + 1] : 0;
+		*dst++ = (uint8_t)(lo | (hi << 4));
+	}
+	if (info->type == SO_PLANE_NORMAL_RLE)
+		dst = put_rle(info->mins_mask, info->mins, dst); /* :765 */
+	else
+		for (int r = 0; r < lines; ++r) {
+			int h = info->hdr[r];
+			if (h != 6 && h != 7 && h != 15)
+				*dst++ = info->mins[r];
+		}
+	for (int r = 0; r < lines; ++r)
+		dst = put_row(p, r, info, dst);
+	return dst;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * mini-LZ, lz_compress.h
+ * ---------------------------------------------------------------------------------------- */
+
+static uint64_t load_le(const uint8_t* p, int n)
+{
+	uint64_t v = 0;
+	for (int i = 0; i < n; ++i)
+		v |= (uint64_t)p[i] << (8 * i);
+	return v;
+}
+
+/* hash_val / hash_val64, lz_compress.h:47-56 */
+static unsigned lz_hash(uint64_t v, int B)
+{
+	if (B == 8 || B == 6)
+		return (unsigned)((v * 14313749767032793493ULL) >> 56);
+	return (unsigned)(((uint32_t)v * 2654435761U) & 255u);
+}
+
+/* element width choice, lz_compress.h:279-299 */
+static int lz_width(size_t T)
+{
+	if (T > 512)
+		return 0;
+	if (T % 8 == 0)
+		return 8;
+	if (T <= 2 || T % 4 == 0)
+		return 4;
+	if (T % 6 == 0)
+		return 6;
+	if (T % 3 == 0)
+		return 3;
+	return 0;
+}
+
+/* lz_compress<B>, lz_compress.h:191-232 with process2 (:161-189).  The hash table starts empty
+ * (every entry >= count), which is what the unmodified reference does when its uninitialised
+ * table (block_compress.h:1211) is pattern-filled.  Returns bytes produced or 0 on failure. */
+static size_t lz_encode(const uint8_t* in, size_t T, size_t max_size, uint8_t* out)
+{
+	int B = lz_width(T);
+	if (!B)
+		return 0;
+	size_t count = 256 * T / (size_t)B;
+	uint16_t tab[256];
+	for (int i = 0; i < 256; ++i)
+		tab[i] = 0xFFFF;
+	unsigned failed = 0, max_failed = 3;
+	int once = 0;
+	uint8_t* o = out;
+
+	for (size_t i = 0; i < count; i += 8) {
+		uint8_t* flag = o++;
+		*flag = 0;
+		if (failed == max_failed) { /* :206-211 raw group, not hashed */
+			failed = 0;
+			if (--max_failed == 0)
+				max_failed = 1;
+			memcpy(o, in + i * B, (size_t)B * 8);
+			o += B * 8;
+		}
+		else {
+			for (int j = 0; j < 8; ++j) {
+				size_t pos = i + (size_t)j;
+				uint64_t v = load_le(in + pos * B, B);
+				/* hash_8<3> reads 4 bytes for the last four values of a group (:95-98) */
+				uint64_t hv = v;
+				if (B == 3 && j >= 4)
+					hv = load_le(in + pos * B, 4);
+				unsigned h = lz_hash(hv, B);
+				unsigned cand = tab[h];
+				if (cand < pos && load_le(in + (size_t)cand * B, B) == v) {
+					unsigned dist = (unsigned)(pos - cand);
+					*flag |= (uint8_t)(1u << j);
+					if (dist < 128)
+						*o++ = (uint8_t)dist;
+					else { /* write_diff, :140-151 */
+						*o++ = (uint8_t)((dist & 127) | 128);
+						*o++ = (uint8_t)(dist >> 7);
+					}
+				}
+				else {
+					memcpy(o, in + pos * B, (size_t)B);
+					o += B;
+				}
+				tab[h] = (uint16_t)pos;
+			}
+			failed += (*flag == 0);
+		}
+		size_t produced = (size_t)(o - out);
+		if (produced > max_size)
+			return 0;
+		if (!once && i > count / 4) { /* :224-229 */
+			if ((double)produced > (double)max_size * 0.4)
+				return 0;
+			once = 1;
+		}
+	}
+	return (size_t)(o - out);
+}
+
+/* lz_decompress<B>, lz_compress.h:234-277; returns bytes consumed or 0 */
+static size_t lz_decode(const uint8_t* in, size_t in_size, size_t T, uint8_t* dst)
+{
+	int B = lz_width(T);
+	if (!B)
+		return 0;
+	size_t count = 256 * T / (size_t)B;
+	const uint8_t* s = in;
+	const uint8_t* end = in + in_size;
+	uint8_t* d = dst;
+	for (size_t i = 0; i < count; i += 8) {
+		if (s + 2 > end)
+			return 0;
+		unsigned flag = *s++;
+		if (flag == 0) {
+			if (s + 8 * B > end)
+				return 0;
+			memcpy(d, s, (size_t)B * 8);
+			d += 8 * B;
+			s += 8 * B;
+			continue;
+		}
+		for (int j = 0; j < 8; ++j) {
+			if ((flag >> j) & 1) {
+				unsigned off = *s & 127u;
+				if (*s++ > 127u) {
+					if (s == end)
+						return 0;
+					off |= (unsigned)(*s++) << 7;
+				}
+				if ((size_t)off * (size_t)B > (size_t)(d - dst) || off == 0)
+					return 0; /* the reference only asserts this in debug builds (:264) */
+				memmove(d, d - (size_t)off * B, (size_t)B);
+				d += B;
+			}
+			else {
+				if (s + B > end)
+					return 0;
+				memcpy(d, s, (size_t)B);
+				d += B;
+				s += B;
+			}
+		}
+	}
+	return (size_t)(s - in);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * block encoder
+ * ---------------------------------------------------------------------------------------- */
+
+static void gather_plane(const uint8_t* block, size_t T, size_t i, uint8_t plane[256])
+{
+	for (int e = 0; e < 256; ++e)
+		plane[e] = block[(size_t)e * T + i];
+}
+
+/* One full block without capacity checks, block_compress.h:1178-1258.  Plane infos are returned
+ * through `infos` (T entries) so that the caller can apply the reference's capacity rules. */
+static size_t analyse_block(const uint8_t* block, size_t T, so_plane_info* infos)
+{
+	uint8_t plane[256];
+	size_t full = 0;
+	for (size_t i = 0; i < T; ++i) {
+		gather_plane(block, T, i, plane);
+		so_analyse_plane(plane, 1, &infos[i]);
+		if (infos[i].size > 256) { /* target = 256 - diff[2], :1190, 1200-1204 */
+			infos[i].type = SO_PLANE_RAW;
+			infos[i].size = 256;
+		}
+		full += infos[i].size;
+	}
+	return full;
+}
+
+static uint8_t* emit_planes(const uint8_t* block, size_t T, const so_plane_info* infos, uint8_t* dst)
+{
+	uint8_t plane[256];
+	size_t hs = (T + 1) / 2;
+	uint8_t* anchor = dst;
+	memset(anchor, 0, hs);
+	dst += hs;
+	for (size_t i = 0; i < T; ++i) {
+		gather_plane(block, T, i, plane);
+		if (infos[i].type == SO_PLANE_RAW) {
+			memcpy(dst, plane, 256);
+			dst += 256;
+		}
+		else
+			dst = put_plane(plane, &infos[i], 16, dst);
+		anchor[i >> 1] |= (uint8_t)(infos[i].type << (4 * (i & 1))); /* :1246-1257 */
+	}
+	return dst;
+}
+
+size_t so_encode_block(const uint8_t* block, size_t T, uint8_t* out, int allow_lz)
+{
+	so_plane_info* infos = (so_plane_info*)malloc(sizeof(so_plane_info) * T);
+	if (!infos)
+		return SO_ERROR_ALLOC;
+	size_t full = analyse_block(block, T, infos);
+	size_t r;
+	if (allow_lz && T % 4 == 0 && full * 3 > 256 * T) { /* :1210 */
+		size_t n = lz_encode(block, T, full, out + 1);
+		if (n) {
+			out[0] = SO_BLOCK_LZ;
+			free(infos);
+			return n + 1;
+		}
+	}
+	r = (size_t)(emit_planes(block, T, infos, out) - out);
+	free(infos);
+	return r;
+}
+
+/* block_compress_partial, block_compress.h:947-1020 */
+static size_t partial_compress(const uint8_t* src, size_t T, size_t n, uint8_t* dst, size_t dst_size)
+{
+	size_t line = 16 * T, lines = n / line, hs = (T + 1) / 2;
+	uint8_t* d = dst;
+	uint8_t* end = dst + dst_size;
+	if (lines) {
+		uint8_t* buf = (uint8_t*)malloc(256 * T);
+		if (!buf)
+			return SO_ERROR_ALLOC;
+		memcpy(buf, src, n);
+		memset(buf + n, buf[n - 1], 256 * T - n); /* pad with the last byte, :967-968 */
+		uint8_t* anchor = d;
+		d += hs;
+		for (size_t i = 0; i < T; ++i) {
+			uint8_t plane[256];
+			so_plane_info info;
+			gather_plane(buf, T, i, plane);
+			so_analyse_plane(plane, 0, &info); /* rle disabled, :982 */
+			if (info.type == SO_PLANE_SAME) {
+				if (d >= end) {
+					free(buf);
+					return SO_ERROR_DST_OVERFLOW;
+				}
+				*d++ = plane[0];
+			}
+			else {
+				size_t size = 8;
+				for (size_t j = 0; j < lines; ++j)
+					size += info.cost[j];
+				if ((size_t)(end - d) < size + 8 || d > end) { /* :993-995 */
+					free(buf);
+					return SO_ERROR_DST_OVERFLOW;
+				}
+				d = put_plane(plane, &info, (int)lines, d);
+			}
+			if ((i & 1) == 0)
+				anchor[i >> 1] = 0;
+			anchor[i >> 1] |= (uint8_t)(info.type << (4 * (i & 1)));
+		}
+		free(buf);
+	}
+	size_t rem = n - lines * line;
+	if (rem) {
+		if (d > end || (size_t)(end - d) < rem)
+			return SO_ERROR_DST_OVERFLOW;
+		memcpy(d, src + lines * line, rem);
+		d += rem;
+	}
+	return (size_t)(d - dst);
+}
+
+/* block_compress, block_compress.h:1099-1302, block_level 2, no time limit, not pre-shuffled,
+ * no target ratio.  Capacity arithmetic is done on offsets (the reference compares pointers that
+ * may run past dst_end). */
+size_t so_block_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* dst, size_t dst_size)
+{
+	if (bytes == 0)
+		return 0;
+	size_t hs = (T + 1) / 2, bs = 256 * T, nblocks = bytes / bs;
+	size_t off = 0; /* dst - __dst */
+	so_plane_info* infos = (so_plane_info*)malloc(sizeof(so_plane_info) * T);
+	uint8_t* tmp = (uint8_t*)malloc(bs + hs + 64);
+	if (!infos || !tmp) {
+		free(infos);
+		free(tmp);
+		return SO_ERROR_ALLOC;
+	}
+	size_t result = 0;
+	for (size_t b = 0; b < nblocks; ++b) {
+		const uint8_t* block = src + b * bs;
+		size_t anchor = off;
+		size_t d = off + hs;
+		size_t full = analyse_block(block, T, infos);
+
+		if (T % 4 == 0 && full * 3 > bs) {
+			/* dst_end > dst + full + 8T + 2, :1214 */
+			if (dst_size > d + full + T * 8 + 2) {
+				size_t n = lz_encode(block, T, full, tmp);
+				if (n) {
+					dst[anchor] = SO_BLOCK_LZ;
+					memcpy(dst + anchor + 1, tmp, n);
+					off = anchor + 1 + n;
+					continue;
+				}
+			}
+		}
+		if (d + full > dst_size) { /* :1225 */
+			result = SO_ERROR_DST_OVERFLOW;
+			goto done;
+		}
+		/* per-plane checks, :1241 and :1248 */
+		{
+			size_t p = d;
+			for (size_t i = 0; i < T; ++i) {
+				if (infos[i].type == SO_PLANE_RAW)
+					p += 256;
+				else {
+					/* the reference tests the analysed size, which for SAME is 1 */
+					if (p + infos[i].size + 16 > dst_size) {
+						result = SO_ERROR_DST_OVERFLOW;
+						goto done;
+					}
+					p += infos[i].size;
+				}
+				if ((i & 1) == 0 && anchor + (i >> 1) >= dst_size) {
+					result = SO_ERROR_DST_OVERFLOW;
+					goto done;
+				}
+			}
+		}
+		{
+			size_t n = (size_t)(emit_planes(block, T, infos, tmp) - tmp);
+			memcpy(dst + anchor, tmp, n);
+			off = anchor + n;
+		}
+	}
+	{
+		size_t rem = bytes - nblocks * bs;
+		if (rem) {
+			if (off + 2 > dst_size) { /* :1284 */
+				result = SO_ERROR_DST_OVERFLOW;
+				goto done;
+			}
+			dst[off++] = SO_BLOCK_PARTIAL;
+			size_t r = partial_compress(src + nblocks * bs, T, rem, dst + off, dst_size - off);
+			if (so_has_error(r)) {
+				result = r;
+				goto done;
+			}
+			off += r;
+		}
+	}
+	result = off;
+done:
+	free(infos);
+	free(tmp);
+	return result;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * block decoder (scalar semantics, block_compress.h:1488-1879)
+ * ---------------------------------------------------------------------------------------- */
+
+static const int hdr_bits[16] = { 0, 1, 2, 3, 4, 5, 6, 8, 0, 1, 2, 3, 4, 5, 6, 8 };
+
+/* optional coverage counters filled while decoding (so_frame_stats) */
+static uint64_t* g_stats;
+#define STAT(i) do { if (g_stats) g_stats[(i)]++; } while (0)
+
+/* read_16_bits_slow, block_compress.h:1328-1449 */
+static const uint8_t* unpack16(const uint8_t* s, const uint8_t* end, int bits, uint8_t v[16])
+{
+	if ((size_t)(end - s) < (size_t)(2 * bits))
+		return NULL;
+	for (int h = 0; h < 2; ++h) {
+		uint64_t acc = 0;
+		for (int b = 0; b < bits; ++b)
+			acc |= (uint64_t)s[h * bits + b] << (8 * b);
+		for (int k = 0; k < 8; ++k)
+			v[8 * h + k] = (uint8_t)((acc >> (k * bits)) & ((1u << bits) - 1u));
+	}
+	return s + 2 * bits;
+}
+
+/* decode_rle, block_compress.h:1585-1613; out[c] = mask bit c ? previous output : next literal */
+static const uint8_t* get_rle(const uint8_t* s, const uint8_t* end, uint8_t prev, uint8_t out[16])
+{
+	if (end - s < 2)
+		return NULL;
+	unsigned mask = s[0] | ((unsigned)s[1] << 8);
+	s += 2;
+	if ((size_t)(16 - popcnt16(mask)) > (size_t)(end - s))
+		return NULL;
+	for (int c = 0; c < 16; ++c) {
+		if ((mask >> c) & 1)
+			out[c] = prev;
+		else
+			out[c] = *s++;
+		prev = out[c];
+	}
+	return s;
+}
+
+/* decode_block / decode_block_rle / decode_line, block_compress.h:1615-1745.
+ * Decodes `lines` rows of one plane into plane-major out[256]. */
+static const uint8_t* get_plane(const uint8_t* s, const uint8_t* end, int type, int lines, uint8_t out[256])
+{
+	uint8_t hdr[16], mins[16];
+	int nh = lines / 2 + (lines & 1);
+	if (type == SO_PLANE_NORMAL) {
+		if ((size_t)(end - s) < (size_t)(nh + lines)) /* :1702 */
+			return NULL;
+	}
+	else if (end - s < nh)
+		return NULL;
+	for (int r = 0; r < lines; ++r)
+		hdr[r] = (r & 1) ? (uint8_t)(s[r >> 1] >> 4) : (uint8_t)(s[r >> 1] & 15);
+	s += nh;
+	if (type == SO_PLANE_NORMAL_RLE) {
+		s = get_rle(s, end, 0, mins);
+		if (!s)
+			return NULL;
+	}
+	else
+		for (int r = 0; r < lines; ++r)
+			if (hdr[r] != 6 && hdr[r] != 7 && hdr[r] != 15)
+				mins[r] = *s++;
+
+	for (int r = 0; r < lines; ++r) {
+		uint8_t* row = out + 16 * r;
+		uint8_t last = r == 0 ? 0 : out[16 * r - 1];
+		int h = hdr[r];
+		STAT(SO_STAT_ROW_HDR + h);
+		if (h == 15) {
+			if (end - s < 16)
+				return NULL;
+			memcpy(row, s, 16);
+			s += 16;
+		}
+		else if (h == 7) {
+			s = get_rle(s, end, last, row);
+			if (!s)
+				return NULL;
+		}
+		else if (h == 6) {
+			uint8_t d[16];
+			s = get_rle(s, end, 0, d);
+			if (!s)
+				return NULL;
+			for (int c = 0; c < 16; ++c) {
+				last = (uint8_t)(last + d[c]);
+				row[c] = last;
+			}
+		}
+		else {
+			uint8_t v[16];
+			int bits = hdr_bits[h];
+			memset(v, 0, 16);
+			if (bits) {
+				s = unpack16(s, end, bits, v);
+				if (!s)
+					return NULL;
+			}
+			for (int c = 0; c < 16; ++c) {
+				uint8_t x = (uint8_t)(v[c] + mins[r]);
+				if (h >= 8) {
+					last = (uint8_t)(last + x);
+					x = last;
+				}
+				row[c] = x;
+			}
+		}
+	}
+	return s;
+}
+
+static void scatter_plane(const uint8_t plane[256], size_t T, size_t i, int elems, uint8_t* block)
+{
+	for (int e = 0; e < elems; ++e)
+		block[(size_t)e * T + i] = plane[e];
+}
+
+/* block_decompress_partial, block_compress.h:1749-1795 */
+static size_t partial_decompress(const uint8_t* src, size_t size, size_t T, size_t n, uint8_t* dst)
+{
+	const uint8_t* s = src;
+	const uint8_t* end = src + size;
+	size_t line = 16 * T, lines = n / line, hs = (T + 1) / 2;
+	if (lines) {
+		const uint8_t* anchor = s;
+		if ((size_t)(end - s) <= hs) /* src += header_len; src >= end, :1764-1766 */
+			return SO_ERROR_SRC_OVERFLOW;
+		s += hs;
+		for (size_t i = 0; i < T; ++i) {
+			uint8_t plane[256];
+			int type = (anchor[i >> 1] >> (4 * (i & 1))) & 15;
+			if (type == SO_PLANE_SAME) {
+				if (s >= end)
+					return SO_ERROR_SRC_OVERFLOW;
+				memset(plane, *s++, 256);
+			}
+			else if (type == SO_PLANE_NORMAL) {
+				s = get_plane(s, end, type, (int)lines, plane);
+				if (!s)
+					return SO_ERROR_SRC_OVERFLOW;
+			}
+			else
+				return SO_ERROR_INVALID_INPUT;
+			scatter_plane(plane, T, i, (int)lines * 16, dst);
+		}
+	}
+	size_t rem = n - lines * line;
+	if (rem) {
+		if ((size_t)(end - s) < rem)
+			return SO_ERROR_SRC_OVERFLOW;
+		memcpy(dst + lines * line, s, rem);
+		s += rem;
+	}
+	return (size_t)(s - src);
+}
+
+/* block_decompress, block_compress.h:1797-1879 */
+size_t so_block_decompress(const uint8_t* src, size_t size, size_t T, size_t bytes, uint8_t* dst)
+{
+	if (bytes == 0 || size == 0)
+		return 0;
+	const uint8_t* s = src;
+	const uint8_t* end = src + size;
+	size_t hs = (T + 1) / 2, bs = 256 * T, nblocks = bytes / bs;
+	if (size < hs + T && nblocks)
+		return SO_ERROR_SRC_OVERFLOW;
+	for (size_t b = 0; b < nblocks; ++b, dst += bs) {
+		const uint8_t* anchor = s;
+		if ((size_t)(end - s) <= hs)
+			return SO_ERROR_SRC_OVERFLOW;
+		s += hs;
+		if (*anchor == SO_BLOCK_COPY) {
+			s = anchor + 1;
+			if ((size_t)(end - s) < bs)
+				return SO_ERROR_SRC_OVERFLOW; /* the reference does not check this */
+			memcpy(dst, s, bs);
+			s += bs;
+			continue;
+		}
+		if (*anchor == SO_BLOCK_LZ) {
+			STAT(SO_STAT_LZ_BLOCKS);
+			s = anchor + 1;
+			size_t n = lz_decode(s, (size_t)(end - s), T, dst);
+			if (!n)
+				return SO_ERROR_INVALID_INPUT;
+			s += n;
+			continue;
+		}
+		for (size_t i = 0; i < T; ++i) {
+			uint8_t plane[256];
+			int type = (anchor[i >> 1] >> (4 * (i & 1))) & 15;
+			if (type < 4)
+				STAT(SO_STAT_PLANE_TYPE + type);
+			switch (type) {
+				case SO_PLANE_RAW:
+					if (end - s < 256)
+						return SO_ERROR_SRC_OVERFLOW;
+					memcpy(plane, s, 256);
+					s += 256;
+					break;
+				case SO_PLANE_SAME:
+					if (s >= end)
+						return SO_ERROR_SRC_OVERFLOW;
+					memset(plane, *s++, 256);
+					break;
+				case SO_PLANE_NORMAL:
+				case SO_PLANE_NORMAL_RLE:
+					s = get_plane(s, end, type, 16, plane);
+					if (!s)
+						return SO_ERROR_SRC_OVERFLOW;
+					break;
+				default:
+					return SO_ERROR_INVALID_INPUT;
+			}
+			scatter_plane(plane, T, i, 256, dst);
+		}
+	}
+	size_t rem = bytes - nblocks * bs;
+	if (rem) {
+		if (s == end)
+			return SO_ERROR_SRC_OVERFLOW;
+		if (*s++ != SO_BLOCK_PARTIAL)
+			return SO_ERROR_INVALID_INPUT;
+		STAT(SO_STAT_PARTIAL_BLOCKS);
+		size_t r = partial_decompress(s, (size_t)(end - s), T, rem, dst);
+		if (so_has_error(r))
+			return r;
+		s += r;
+	}
+	return (size_t)(s - src);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * zstd through dlopen (only for superblocks < 128 bytes and for decoding code 2)
+ * ---------------------------------------------------------------------------------------- */
+
+typedef size_t (*zstd_compress_fn)(void*, size_t, const void*, size_t, int);
+typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_iserror_fn)(size_t);
+static zstd_compress_fn z_compress;
+static zstd_decompress_fn z_decompress;
+static zstd_iserror_fn z_iserror;
+
+static int load_zstd(void)
+{
+	static int state; /* 0 unknown, 1 ok, -1 missing */
+	if (state)
+		return state > 0;
+	const char* names[] = { "/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", NULL };
+	void* h = NULL;
+	for (int i = 0; names[i] && !h; ++i)
+		h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+	if (h) {
+		z_compress = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
+		z_decompress = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+		z_iserror = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+	}
+	state = (z_compress && z_decompress && z_iserror) ? 1 : -1;
+	return state > 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * frame + superblocks
+ * ---------------------------------------------------------------------------------------- */
+
+static void put_le(uint8_t* p, uint64_t v, int n)
+{
+	for (int i = 0; i < n; ++i)
+		p[i] = (uint8_t)(v >> (8 * i));
+}
+
+/* compress_memcpy, stenos.cpp:363-374 */
+static size_t sb_copy(const uint8_t* src, size_t bytes, uint8_t* dst, size_t dst_size)
+{
+	if (dst_size < bytes + 4)
+		return SO_ERROR_DST_OVERFLOW;
+	dst[0] = 6;
+	put_le(dst + 1, bytes, 3);
+	memcpy(dst + 4, src, bytes);
+	return bytes + 4;
+}
+
+/* compress_generic_superblock, stenos.cpp:403-450, 606-615, 658-678 (level 0/1, bytesoftype > 1) */
+static size_t sb_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, int level)
+{
+	if (dst_size < 4)
+		return SO_ERROR_DST_OVERFLOW;
+	if (bytes == 0 || level == 0)
+		return sb_copy(src, bytes, dst, dst_size);
+	if (bytes < 128) { /* :435-437 -> ZSTD with zstd level 1 (zstd_wrapper.h:49-56) */
+		if (!load_zstd())
+			return SO_ERROR_ZSTD_INTERNAL;
+		size_t r = z_compress(dst + 4, dst_size - 4, src, bytes, 1);
+		if (z_iserror(r) || r > bytes)
+			return sb_copy(src, bytes, dst, dst_size);
+		dst[0] = 2;
+		put_le(dst + 1, r, 3);
+		return r + 4;
+	}
+	size_t r = so_block_compress(src, T, bytes, dst + 4, dst_size - 4);
+	if (so_has_error(r) || r > bytes) /* equal is kept, :609 */
+		return sb_copy(src, bytes, dst, dst_size);
+	dst[0] = 1;
+	put_le(dst + 1, r, 3);
+	return r + 4;
+}
+
+/* stenos_compress -> stenos_compress_generic serial path, stenos.cpp:844-907, 1210-1218 */
+size_t so_compress(const void* _src, size_t T, size_t bytes, void* _dst, size_t dst_size, int level)
+{
+	const uint8_t* src = (const uint8_t*)_src;
+	uint8_t* dst = (uint8_t*)_dst;
+	if (level > 9) level = 9;
+	if (level < 0) level = 0;
+	if (T == 0 || T >= MAX_BYTESOFTYPE) /* :119-120 */
+		return SO_ERROR_INVALID_BYTESOFTYPE;
+	if (level > 1 || T == 1)
+		return SO_ERROR_INVALID_PARAMETER; /* outside the oracle's scope (see header) */
+	size_t bs = 256 * T, sb = base_superblock(bs);
+	unsigned shift = 0;
+	if (bytes > sb) {
+		shift = level ? (unsigned)(level - 1) / 2 : 0;
+		sb <<= shift;
+	}
+	if (sb < bs || sb >= SB_MAX) /* :168-169 */
+		return SO_ERROR_INVALID_PARAMETER;
+	if (dst_size < 8)
+		return SO_ERROR_DST_OVERFLOW;
+	dst[0] = (uint8_t)shift;
+	put_le(dst + 1, bytes, 7);
+	size_t off = 8;
+	if (bytes == 0)
+		return off;
+	size_t nsb = bytes / sb + (bytes % sb ? 1 : 0);
+	for (size_t i = 0; i < nsb; ++i) {
+		size_t in = (i == nsb - 1) ? bytes - i * sb : sb;
+		size_t r = sb_compress(src + i * sb, T, in, dst + off, dst_size - off, level);
+		if (so_has_error(r))
+			return r;
+		off += r;
+	}
+	return off;
+}
+
+/* stenos_decompress -> stenos_decompress_generic serial path, stenos.cpp:1052-1149, and
+ * decompress_generic_superblock, stenos.cpp:681-753 (codes 1, 2, 6) */
+size_t so_decompress(const void* _src, size_t T, size_t size, void* _dst, size_t dst_size, int fix_exact_multiple)
+{
+	const uint8_t* s = (const uint8_t*)_src;
+	const uint8_t* end = s + size;
+	uint8_t* dst = (uint8_t*)_dst;
+	if (T == 0 || T >= MAX_BYTESOFTYPE)
+		return SO_ERROR_INVALID_BYTESOFTYPE;
+	if (size < 8)
+		return SO_ERROR_SRC_OVERFLOW;
+	unsigned shift = *s++;
+	if (shift > 4 && shift != 255)
+		return SO_ERROR_INVALID_INPUT;
+	uint64_t total = load_le(s, 7);
+	s += 7;
+	if (total > dst_size)
+		return SO_ERROR_DST_OVERFLOW;
+	if (total == 0)
+		return 0;
+	size_t sb;
+	if (shift == 255) {
+		if (end - s < 4)
+			return SO_ERROR_SRC_OVERFLOW;
+		sb = (size_t)load_le(s, 4);
+		s += 4;
+		if (sb == 0)
+			return SO_ERROR_INVALID_INPUT; /* the reference divides by zero here */
+	}
+	else
+		sb = base_superblock(256 * T) << shift;
+	size_t rem = (size_t)(total % sb);
+	size_t nsb = (size_t)(total / sb) + (rem ? 1 : 0);
+	size_t done = 0;
+	for (size_t i = 0; i < nsb; ++i) {
+		if (end - s < 4)
+			return SO_ERROR_SRC_OVERFLOW;
+		unsigned code = *s++;
+		size_t csize = (size_t)load_le(s, 3);
+		s += 3;
+		size_t dsize = (i == nsb - 1) ? rem : sb; /* stenos.cpp:1131: 0 for exact multiples */
+		if (fix_exact_multiple && dsize == 0)
+			dsize = sb;
+		if ((size_t)(end - s) < csize || done + dsize > dst_size)
+			return SO_ERROR_INVALID_INPUT;
+		if (code < 8)
+			STAT(SO_STAT_SB_CODE + code);
+		switch (code) {
+			case 1: {
+				size_t r = so_block_decompress(s, csize, T, dsize, dst + done);
+				if (so_has_error(r))
+					return SO_ERROR_INVALID_INPUT;
+			} break;
+			case 2: {
+				if (!load_zstd())
+					return SO_ERROR_ZSTD_INTERNAL;
+				size_t r = z_decompress(dst + done, dsize, s, csize);
+				if (z_iserror(r))
+					return SO_ERROR_INVALID_INPUT;
+			} break;
+			case 6:
+				if (dsize != csize)
+					return SO_ERROR_INVALID_INPUT;
+				memcpy(dst + done, s, csize);
+				break;
+			default:
+				return SO_ERROR_INVALID_INPUT; /* codes 3-5 are outside the oracle's scope */
+		}
+		done += dsize;
+		s += csize;
+	}
+	if (done != total)
+		return SO_ERROR_INVALID_INPUT;
+	return (size_t)total;
+}
+
+/* decode a frame into a scratch buffer and count what the stream contains (test coverage) */
+size_t so_frame_stats(const void* src, size_t T, size_t size, uint64_t counts[SO_STAT_COUNT])
+{
+	if (size < 8)
+		return SO_ERROR_SRC_OVERFLOW;
+	uint64_t total = load_le((const uint8_t*)src + 1, 7);
+	uint8_t* tmp = (uint8_t*)malloc((size_t)total + 1);
+	if (!tmp)
+		return SO_ERROR_ALLOC;
+	memset(counts, 0, sizeof(uint64_t) * SO_STAT_COUNT);
+	g_stats = counts;
+	size_t r = so_decompress(src, T, size, tmp, (size_t)total, 1);
+	g_stats = NULL;
+	free(tmp);
+	return r;
+}

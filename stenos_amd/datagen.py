@@ -1,0 +1,104 @@
+"""Seeded synthetic typed-array generators shared by tests, golden fixtures and bench.py.
+
+All integer generators are built on splitmix64 (one draw per element), so that numpy on the
+host and torch on the device produce the same bytes (SURVEY.md section 8d proposes this generator;
+the reference itself only has std::mt19937-based test inputs, tests/tests_comp_decomp.cpp:37-86).
+
+    s += 0x9E3779B97F4A7C15; z = s
+    z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9
+    z = (z ^ z >> 27) * 0x94D049BB133111EB
+    u = z ^ z >> 31                                   (all mod 2**64)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(seed: int, n: int, start: int = 0) -> np.ndarray:
+    """u[i] for i in [start, start+n): the (i+1)-th output of splitmix64 seeded with `seed`."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _as_bytes(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+
+
+def _le_elements(x: np.ndarray, T: int) -> np.ndarray:
+    """int64 values -> n elements of T little-endian bytes (sign-extended above 8 bytes)."""
+    n = x.shape[0]
+    b = np.ascontiguousarray(x.astype("<i8")).view(np.uint8).reshape(n, 8)
+    out = np.empty((n, T), dtype=np.uint8)
+    k = min(T, 8)
+    out[:, :k] = b[:, :k]
+    if T > 8:
+        out[:, 8:] = np.where(x[:, None] < 0, 255, 0).astype(np.uint8)
+    return out.reshape(-1)
+
+
+def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
+    """Return n elements of T bytes as a flat uint8 array.
+
+    kinds: sorted_i32 (README example, T=4), rand (full entropy), rand12 (u & 0xFFF, T=4),
+    same, sorted (lexicographically sorted random elements, signed bytes as std::array<char,N>),
+    walk (x += u%17 - 8), dict16 (16-entry dictionary), runs (runs of 7), burst, ramp,
+    sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal).
+    """
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8)
+    u = splitmix64(seed, n)
+    if kind == "sorted_i32":
+        assert T == 4
+        return _as_bytes(np.arange(n, dtype="<i4"))
+    if kind == "rand":
+        m = splitmix64(seed, (n * T + 7) // 8)
+        return _as_bytes(m)[: n * T].copy()
+    if kind == "rand12":
+        assert T == 4
+        return _as_bytes((u & np.uint64(0xFFF)).astype("<u4"))
+    if kind == "same":
+        return np.full(n * T, int(u[0] & np.uint64(0xFF)), dtype=np.uint8)
+    if kind == "sorted":
+        a = generate("rand", T, n, seed).reshape(n, T)
+        order = np.lexsort(a.view(np.int8).T[::-1])
+        return np.ascontiguousarray(a[order]).reshape(-1)
+    if kind == "walk":
+        steps = (u % np.uint64(17)).astype(np.int64) - 8
+        return _le_elements(np.cumsum(steps), T)
+    if kind == "ramp":
+        return _le_elements(np.arange(n, dtype=np.int64) * 3 + 1000, T)
+    if kind == "dict16":
+        d = generate("rand", T, 16, seed + 1).reshape(16, T)
+        return np.ascontiguousarray(d[(u & np.uint64(15)).astype(np.int64)]).reshape(-1)
+    if kind == "runs":
+        v = generate("rand", T, n // 7 + 1, seed + 1).reshape(-1, T)
+        return np.ascontiguousarray(np.repeat(v, 7, axis=0)[:n]).reshape(-1)
+    if kind == "burst":
+        # mostly-constant elements with short random bursts and a slow step pattern
+        a = np.zeros((n, T), dtype=np.uint8)
+        hot = (u % np.uint64(50)) == 0
+        burst = np.convolve(hot.astype(np.int32), np.ones(9, dtype=np.int32))[:n] > 0
+        r = generate("rand", T, n, seed + 2).reshape(n, T)
+        a[burst] = r[burst] & 0x3F
+        a += ((np.arange(n) // 64) % 3).astype(np.uint8)[:, None]
+        return a.reshape(-1)
+    if kind == "sine":
+        x = np.sin(np.arange(n, dtype=np.float64) * 0.001)
+        if T == 8:
+            return _as_bytes(x.astype("<f8"))
+        if T == 4:
+            return _as_bytes(x.astype("<f4"))
+        raise ValueError("sine needs T in (4, 8)")
+    if kind == "smooth8":
+        assert T == 1
+        x = (128 + 100 * np.sin(0.01 * np.arange(n))).astype(np.int64) + (u % np.uint64(5)).astype(np.int64) - 2
+        return (x & 0xFF).astype(np.uint8)
+    raise ValueError(f"unknown kind {kind}")
