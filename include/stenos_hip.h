@@ -1,0 +1,48 @@
+/*
+ * stenos_hip.h -- device-resident entry points of libstenos.so (additions next to the frozen ABI of
+ * stenos.h; the reference has no counterpart: its hot loop stenos_compress_generic,
+ * stenos/internal/stenos.cpp:884-1010, and stenos_decompress_generic, :1118-1202, only take host
+ * pointers).  Source and destination are DEVICE pointers; nothing crosses PCIe except the 8-byte
+ * result.  Plain C: pointers and sizes only, `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).
+ */
+#ifndef STENOS_HIP_H
+#define STENOS_HIP_H
+#include "stenos.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of HIP devices visible, 0 when the runtime is unusable */
+STENOS_EXPORT int stenos_hip_device_count(void);
+
+/* Bytes of device workspace the two calls below need for `bytes` of input (scratch slots, size and
+ * offset tables).  The context allocates and keeps it; this is for capacity planning. */
+STENOS_EXPORT size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes);
+
+/* Compress `bytes` of device memory into a Stenos frame in device memory.  Uses ctx's level and
+ * block-size settings.  Enqueues on `stream`, then waits for the 8-byte size to come back.
+ * Returns the frame size or an error code (test with stenos_has_error). */
+STENOS_EXPORT size_t stenos_hip_compress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream);
+
+/* Same, without waiting: the result is read by stenos_hip_finish().  The frame bytes in d_dst and
+ * the index are valid once the stream has executed the enqueued work. */
+STENOS_EXPORT size_t stenos_hip_compress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream);
+STENOS_EXPORT size_t stenos_hip_finish(stenos_context* ctx);
+
+/* Superblock index of the last compression on ctx: device array of nsb + 1 uint64 byte offsets of the
+ * superblock headers inside the frame (the last entry is the frame size).  Valid until the next call on ctx. */
+STENOS_EXPORT const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb);
+
+/* Decompress a frame held in device memory.  d_index may be NULL: the superblock chain
+ * ([code][csize:3] headers, reference stenos.cpp:1129-1134) is then walked on the device first
+ * (serial, latency bound); passing the index produced by stenos_hip_last_index() skips that walk.
+ * Returns the decompressed size or an error code. */
+STENOS_EXPORT size_t stenos_hip_decompress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
+STENOS_EXPORT size_t stenos_hip_decompress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,852 @@
+// block_codec.h -- the Stenos 256-element block codec, one wavefront per block, written in the
+// wavevec.h vocabulary (gfx950 device code; the same source runs as a lockstep host emulation in tests).
+//
+// Bit stream (reference: stenos/internal/block_compress.h, lz_compress.h):
+//   full block  = [ceil(T/2) plane-type nibbles][plane 0]...[plane T-1]   or   [253][mini-LZ stream]
+//   plane       = SAME [v] | RAW [256 bytes] | NORMAL [8 B row headers][mins][rows] | NORMAL_RLE [8 B][mask16][mins][rows]
+//   row payload = 16 raw | rle [mask16][literals] | delta-rle | two halves of 8 values packed LSB first
+//
+// Lane mapping.  "Element lanes": lane l owns elements 4l..4l+3 of the block, so one row of 16
+// elements is one quad of lanes and a plane's 4 bytes per lane travel as one packed dword.
+// "Row lanes": lane 16*p + r owns row r of plane p of the current group of four planes; per-row
+// decisions (bit widths, rle, headers, offsets) are taken once there for four planes at a time.
+// The two views exchange data through the wave's private LDS scratch.
+//
+// Everything written to the output goes through lds_put_bits() (an OR into a zeroed LDS image), so
+// pieces of any bit length land at any byte offset without read-modify-write ordering problems.
+#pragma once
+#include "wavevec.h"
+
+namespace codec {
+using namespace wv;
+
+enum { PLANE_SAME = 0, PLANE_RAW = 1, PLANE_NORMAL = 2, PLANE_NORMAL_RLE = 3 };
+enum { BLOCK_COPY = 252, BLOCK_LZ = 253, BLOCK_PARTIAL = 254 };
+constexpr uint32_t LZ_NONE = 0xFFFFFFFFu;
+constexpr uint32_t MAX_T = 64; // largest bytesoftype handled by the LDS-resident codec
+
+// Byte offsets of the regions of one wave's LDS scratch.
+struct Layout {
+	uint32_t in;      // raw block, element major: 256*T bytes (+8 slack)
+	uint32_t out;     // encoded image: out_capacity(T) bytes, zeroed by the codec
+	uint32_t rowinfo; // T*16 entries of 8 bytes
+	uint32_t plinfo;  // T entries of 4 bytes
+	uint32_t aux;     // 64 entries of 8 bytes (row statistics of the current plane group) / decoder scratch
+	uint32_t lz;      // mini-LZ: table 256*4 + chain count*4 + cur count*4
+	uint32_t total;
+};
+
+WV_HD uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+WV_HD uint32_t lz_width(uint32_t T) { return (T % 8 == 0) ? 8u : 4u; } // lz_compress.h:285-290 for T%4==0
+WV_HD uint32_t header_bytes(uint32_t T) { return (T + 1) >> 1; }
+// a partial block can take 1 + T/2 + T*(8 + 15*17) + (16*T - 1) bytes, more than a full one
+WV_HD uint32_t out_capacity(uint32_t T) { return align16(280 * T + header_bytes(T) + 40); }
+
+WV_HD Layout make_layout(uint32_t T, bool with_lz)
+{
+	Layout L;
+	uint32_t o = 0;
+	L.in = o;
+	o += align16(256 * T + 16);
+	L.out = o;
+	o += out_capacity(T);
+	L.rowinfo = o;
+	o += T * 16 * 8;
+	L.plinfo = o;
+	o += align16(T * 4);
+	L.aux = o;
+	o += 64 * 8;
+	L.lz = o;
+	if (with_lz && T % 4 == 0) {
+		uint32_t count = 256 * T / lz_width(T);
+		o += 256 * 4 + count * 8;
+	}
+	L.total = align16(o);
+	return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+
+// the four bytes of plane j owned by this element lane: elements 4l..4l+3
+WV_FN U32 fetch_plane_word(Lds lds, uint32_t in, uint32_t T, uint32_t j)
+{
+	U32 l = lane_id();
+	if (T == 4) { // one dword per element
+		U32 a = U32(in) + l * 16u;
+		U32 sh = U32(8u * j);
+		U32 e0 = (lds_ld32(lds, a) >> sh) & 0xFFu;
+		U32 e1 = (lds_ld32(lds, a + 4u) >> sh) & 0xFFu;
+		U32 e2 = (lds_ld32(lds, a + 8u) >> sh) & 0xFFu;
+		U32 e3 = (lds_ld32(lds, a + 12u) >> sh) & 0xFFu;
+		return e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+	}
+	U32 a = U32(in + j) + l * (4u * T);
+	U32 b0 = lds_ld8(lds, a);
+	U32 b1 = lds_ld8(lds, a + T);
+	U32 b2 = lds_ld8(lds, a + 2u * T);
+	U32 b3 = lds_ld8(lds, a + 3u * T);
+	return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
+WV_FN U32 min4(const U32& x) { return umin(umin(byte_of(x, 0), byte_of(x, 1)), umin(byte_of(x, 2), byte_of(x, 3))); }
+WV_FN U32 max4(const U32& x) { return umax(umax(byte_of(x, 0), byte_of(x, 1)), umax(byte_of(x, 2), byte_of(x, 3))); }
+
+// W(): bits needed for a byte range with 7 promoted to 8 (block_compress.h:334-352)
+WV_FN U32 width_of(const U32& range)
+{
+	U32 b = bitlen(range);
+	return sel(b >= U32(7u), U32(8u), b);
+}
+
+// per-lane pieces every plane pass needs: packed bytes w, packed deltas dw (previous byte in plane
+// order, 0 before the plane's first byte), zero masks of the deltas (rle) and of the delta differences
+// (delta-rle, previous delta of a row's first column is 0)
+struct PlaneWords {
+	U32 w, dw, z1, z2;
+};
+WV_FN PlaneWords plane_words(const U32& w)
+{
+	PlaneWords p;
+	p.w = w;
+	U32 prevb = shfl_up(w, 1, 0) >> 24; // lane 0: 0  (block_compress.h:399-401)
+	p.dw = bytes_sub(w, (w << 8) | prevb);
+	p.z1 = bytes_zero_mask(p.dw); // byte == previous byte  (:268-275)
+	U32 pd = sel((lane_id() & 3u) == U32(0u), U32(0u), shfl_up(p.dw, 1, 0) >> 24);
+	p.z2 = bytes_zero_mask(p.dw ^ ((p.dw << 8) | pd)); // delta == previous delta  (:248-255, 449-458)
+	return p;
+}
+
+// keep the bytes of x whose flag bit (bits 0..3 of f) is 0, packed towards the low end
+WV_FN U32 compact_unflagged(const U32& x, const U32& f)
+{
+	U32 out(0u), n(0u);
+	for (int k = 0; k < 4; ++k) {
+		Pred keep = ((f >> U32((uint32_t)k)) & 1u) == U32(0u);
+		out = out | sel(keep, byte_of(x, k) << (n << 3), U32(0u));
+		n = n + sel(keep, U32(1u), U32(0u));
+	}
+	return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+
+// rowinfo entry: lo = hdr | min<<8 | poff<<16 ; hi = minpos | emitmin<<12 | eq<<13
+// plinfo entry : type | size_or_offset<<8
+
+// Analyse the planes [g, g+np) (np <= 4).  rle: full-block mode (rle + raw override enabled);
+// lines: number of rows that will be emitted (16 for full blocks).
+WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines)
+{
+	const U32 lane = lane_id();
+	// stage 1: element lanes, one plane at a time -> per-row statistics in L.aux
+	for (uint32_t pj = 0; pj < np; ++pj) {
+		PlaneWords p = plane_words(fetch_plane_word(lds, L.in, T, g + pj));
+		U32 cnt = quad_add(popc(p.z1) | (popc(p.z2) << 16));
+		U32 s = p.w ^ 0x80808080u, ds = p.dw ^ 0x80808080u; // signed order (:407-411)
+		U32 mn = quad_min(min4(s)), mx = quad_max(max4(s));
+		U32 dmn = quad_min(min4(ds)), dmx = quad_max(max4(ds));
+		Pred leader = (lane & 3u) == U32(0u);
+		U32 addr = U32(L.aux + pj * 128u) + (lane >> 2) * 8u;
+		lds_st32(lds, addr, mn | (mx << 8) | (dmn << 16) | (dmx << 24), leader);
+		lds_st32(lds, addr + 4u, cnt, leader);
+	}
+	wave_sync();
+
+	// stage 2: row lanes
+	const U32 r = lane & 15u;
+	const U32 pl = lane >> 4;
+	const Pred valid = pl < U32(np);
+	const Pred act = r < U32(lines);
+	U32 lo, hi;
+	lds_ld64(lds, U32(L.aux) + lane * 8u, lo, hi);
+	U32 mn = lo & 0xFFu, mx = (lo >> 8) & 0xFFu, dmn = (lo >> 16) & 0xFFu, dmx = lo >> 24;
+	U32 nrle = hi & 0xFFFFu, ndrle = hi >> 16;
+	U32 b0 = width_of(mx - mn), b1 = width_of(dmx - dmn);
+	b0 = sel(b0 == U32(6u), U32(8u), b0); // header 6 is reserved for delta-rle (:422)
+	U32 bits = umin(b0, b1);
+	Pred type0 = b0 == bits; // ties go to frame-of-reference (:423-427)
+	U32 minv = sel(type0, mn, dmn) ^ 0x80u;
+	U32 cost = bits * 2u + sel(bits != U32(8u), U32(1u), U32(0u)); // (:433-435)
+	U32 hdr = sel(type0, sel(b0 == U32(8u), U32(15u), b0), b1 + 8u); // (:497-503)
+	if (rle) {
+		U32 c1 = U32(18u) - nrle; // 2 + 16 - popcnt, strictly smaller wins (:464-467)
+		Pred u1 = c1 < cost;
+		cost = sel(u1, c1, cost);
+		hdr = sel(u1, U32(7u), hdr);
+		U32 c2 = U32(18u) - ndrle; // (:470-472)
+		Pred u2 = c2 < cost;
+		cost = sel(u2, c2, cost);
+		hdr = sel(u2, U32(6u), hdr);
+	}
+	Pred nomin = (hdr == U32(6u)) | (hdr == U32(7u)) | (hdr == U32(15u));
+	Pred eq = minv == row_shr(minv, 1, 0); // min equals previous row's min, 0 before row 0 (:483)
+	Pred rowsame = (mx == mn) & ((r == U32(0u)) | eq);
+
+	U32 packed = sel(act, cost, U32(0u)) | sel(act & nomin, U32(1u << 12), U32(0u)) | sel(eq, U32(1u << 17), U32(0u)) |
+		     sel(rowsame, U32(1u << 22), U32(0u));
+	U32 tot = row_add(packed);
+	U32 sumcost = tot & 0xFFFu, count8 = (tot >> 12) & 31u, eqc = (tot >> 17) & 31u, samec = (tot >> 22) & 31u;
+	const uint32_t nh = (lines + 1) >> 1; // row-header bytes: 8 for full blocks
+	U32 size = sumcost + nh;
+	Pred is_same = samec == U32(16u);
+	// mins rle (:478-490): 2 + non-repeated mins < mins that would be written
+	Pred minsrle = pred_all(rle) & ((U32(18u) - eqc) < (U32(16u) - count8));
+	size = sel(minsrle, size - ((U32(16u) - count8) - (U32(18u) - eqc)), size);
+	U32 type = sel(is_same, U32(PLANE_SAME), sel(minsrle, U32(PLANE_NORMAL_RLE), U32(PLANE_NORMAL)));
+	size = sel(is_same, U32(1u), size);
+	if (rle) { // target size 256 (:1190, 1200-1204)
+		Pred raw = size > U32(256u);
+		type = sel(raw, U32(PLANE_RAW), type);
+		size = sel(raw, U32(256u), size);
+	}
+	U32 pay = sel(act, sel(nomin, cost, cost - 1u), U32(0u));
+	Pred emit = act & ((minsrle & !eq) | (!minsrle & !nomin));
+	U32 ex = row_excl_scan(pay | sel(emit, U32(1u << 16), U32(0u)));
+	U32 minslen = sel(minsrle, U32(18u) - eqc, U32(lines) - count8);
+	U32 poff = U32(nh) + minslen + (ex & 0xFFFFu);
+	U32 minpos = U32(nh) + sel(minsrle, U32(2u), U32(0u)) + (ex >> 16);
+
+	U32 ri = U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u;
+	lds_st32(lds, ri, hdr | (minv << 8) | (poff << 16), valid);
+	lds_st32(lds, ri + 4u, minpos | sel(emit, U32(1u << 12), U32(0u)) | sel(eq, U32(1u << 13), U32(0u)), valid);
+	lds_st32(lds, U32(L.plinfo) + (U32(g) + pl) * 4u, type | (size << 8), valid & (r == U32(0u)));
+	wave_sync();
+}
+
+// Turn plane sizes into plane offsets (relative to the block start, after the type nibbles).
+// Returns the sum of the plane sizes ("full_size", block_compress.h:1189-1207).
+WV_FN uint32_t plane_offsets(Lds lds, const Layout& L, uint32_t T)
+{
+	const U32 lane = lane_id();
+	const Pred valid = lane < U32(T);
+	U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
+	U32 size = pi >> 8;
+	U32 incl = wave_incl_scan(size);
+	U32 off = U32(header_bytes(T)) + incl - size;
+	lds_st32(lds, U32(L.plinfo) + lane * 4u, (pi & 0xFFu) | (off << 8), valid);
+	wave_sync();
+	return readlane(incl, 63);
+}
+
+// Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
+WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines)
+{
+	const U32 lane = lane_id();
+	Lds out = lds + L.out;
+	// plane type nibbles (block_compress.h:1246-1257)
+	{
+		Pred valid = lane < U32(T);
+		U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
+		lds_put_bits(out, U32(base * 8u) + lane * 4u, pi & 0xFu, valid);
+	}
+	// row lanes: row-header nibbles, mins, SAME byte
+	for (uint32_t g = 0; g < T; g += 4) {
+		const uint32_t np = T - g < 4 ? T - g : 4;
+		const U32 r = lane & 15u, pl = lane >> 4;
+		const Pred valid = pl < U32(np);
+		U32 lo, hi;
+		lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
+		U32 pi = lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
+		U32 type = pi & 0xFFu;
+		U32 pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
+		Pred normal = valid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
+		Pred act = r < U32(lines);
+		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
+		lds_put_bits(out, pbase * 8u + r * 4u, hdr, normal & act); // (:768-779, 758-762)
+		Pred emit = ((hi >> 12) & 1u) == U32(1u);
+		lds_put_bits(out, (pbase + (hi & 0xFFFu)) * 8u, minv, normal & emit);
+		// mins rle mask (:765): bit r = min equals previous min
+		uint64_t eqb = ballot(((hi >> 13) & 1u) == U32(1u));
+		U32 m16 = sel(pl == U32(0u), U32((uint32_t)(eqb & 0xFFFF)),
+			      sel(pl == U32(1u), U32((uint32_t)((eqb >> 16) & 0xFFFF)),
+				  sel(pl == U32(2u), U32((uint32_t)((eqb >> 32) & 0xFFFF)), U32((uint32_t)(eqb >> 48)))));
+		lds_put_bits(out, (pbase + 8u) * 8u, m16, valid & (type == U32(PLANE_NORMAL_RLE)) & (r == U32(0u)));
+		// SAME: the plane's byte; every row has mx == mn so minv is that byte (:747-750)
+		lds_put_bits(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
+	}
+	// element lanes: row payloads
+	const U32 row = lane >> 2, q = lane & 3u;
+	for (uint32_t j = 0; j < T; ++j) {
+		uint32_t pi = readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
+		uint32_t type = pi & 0xFFu;
+		uint32_t pbase = base + (pi >> 8);
+		if (type == PLANE_SAME)
+			continue;
+		PlaneWords p = plane_words(fetch_plane_word(lds, L.in, T, j));
+		if (type == PLANE_RAW) {
+			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, p.w, pred_all(true));
+			continue;
+		}
+		U32 lo = lds_ld32(lds, U32(L.rowinfo + j * 128u) + row * 8u);
+		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
+		U32 rbase = U32(pbase) + (lo >> 16);
+		Pred act = row < U32(lines);
+		// raw row (:674-676)
+		lds_put_bits(out, (rbase + q * 4u) * 8u, p.w, act & (hdr == U32(15u)));
+		// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
+		{
+			Pred is7 = hdr == U32(7u), is6 = hdr == U32(6u);
+			Pred isr = act & (is7 | is6);
+			if (any(isr)) {
+				U32 f = zero_mask_to_bits(sel(is7, p.z1, p.z2));
+				U32 src = sel(is7, p.w, p.dw);
+				U32 nlit = U32(4u) - popc(f);
+				U32 before = quad_add(sel(isr, nlit << (q << 3), U32(0u))); // per-lane literal counts of the quad
+				U32 prior = (before & ((U32(1u) << (q << 3)) - 1u));
+				prior = (prior & 0xFFu) + ((prior >> 8) & 0xFFu) + ((prior >> 16) & 0xFFu);
+				lds_put_bits(out, rbase * 8u + q * 4u, f, isr);
+				lds_put_bits(out, (rbase + 2u + prior) * 8u, compact_unflagged(src, f), isr & (nlit != U32(0u)));
+			}
+		}
+		// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each
+		{
+			U32 bits = hdr & 7u;
+			Pred isp = act & (hdr != U32(15u)) & (hdr != U32(7u)) & (hdr != U32(6u)) & (bits != U32(0u));
+			U32 v = bytes_sub(sel(hdr < U32(8u), p.w, p.dw), bytes_splat(minv));
+			U32 x = byte_of(v, 0) | (byte_of(v, 1) << bits) | (byte_of(v, 2) << (bits * 2u)) | (byte_of(v, 3) << (bits * 3u));
+			U32 bitpos = (rbase + (q >> 1) * bits) * 8u + (q & 1u) * bits * 4u;
+			lds_put_bits(out, bitpos, x, isp);
+		}
+	}
+	wave_sync();
+}
+
+// zero `bytes` (multiple of 4) of LDS at `off`
+WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
+{
+	const U32 lane = lane_id();
+	for (uint32_t o = 0; o < bytes; o += 256)
+		lds_st32(lds, U32(off + o) + lane * 4u, U32(0u), (U32(o) + lane * 4u) < U32(bytes));
+	wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mini-LZ (lz_compress.h:161-232).  Positions are visited 64 at a time (lane = pos & 63).
+// ------------------------------------------------------------------------------------------------
+
+struct LzVal {
+	U32 lo, hi;
+};
+WV_FN LzVal lz_value(Lds lds, uint32_t in, uint32_t B, const U32& pos)
+{
+	LzVal v;
+	if (B == 8)
+		lds_ld64(lds, U32(in) + pos * 8u, v.lo, v.hi);
+	else {
+		v.lo = lds_ld32(lds, U32(in) + pos * 4u);
+		v.hi = U32(0u);
+	}
+	return v;
+}
+// hash_val / hash_val64 (lz_compress.h:47-56)
+WV_FN U32 lz_hash(const LzVal& v, uint32_t B)
+{
+	if (B == 8) {
+		// (v * 14313749767032793493) >> 56 ; K = 0xC6A4A7935BD1E995
+		const uint32_t klo = 0x5BD1E995u, khi = 0xC6A4A793u;
+		U32 top = v.lo * khi + v.hi * klo + mulhi(v.lo, U32(klo));
+		return top >> 24;
+	}
+	return (v.lo * 2654435761u) & 255u;
+}
+
+// Try to encode the block held at L.in with the mini-LZ.  Returns the number of bytes produced
+// (after the 253 marker) or 0 when the reference would give up.  On success the stream has been
+// written to the zeroed output image at byte base+1 and the marker at base.
+WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base)
+{
+	const U32 lane = lane_id();
+	const uint32_t B = lz_width(T);
+	const uint32_t count = 256 * T / B, nchunks = count / 64;
+	const uint32_t tab = L.lz, chain = L.lz + 1024, cur = chain + count * 4;
+	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
+
+	// empty table: every entry "no position"
+	for (uint32_t o = 0; o < 1024; o += 256)
+		lds_st32(lds, U32(tab + o) + lane * 4u, U32(LZ_NONE), pred_all(true));
+	wave_sync();
+
+	uint32_t failed = 0, max_failed = 3, produced = 0;
+	bool once = false;
+	// skip bits (one per group, up to 256 groups) live in the aux region, free after the analysis
+	const uint32_t skipbits = L.aux;
+	lds_st32(lds, U32(skipbits) + lane * 4u, U32(0u), lane < U32(8u));
+	wave_sync();
+	auto skipped = [&](const U32& h) -> Pred {
+		Pred has = h != U32(LZ_NONE);
+		U32 gidx = sel(has, h >> 3, U32(0u));
+		U32 word = lds_ld32(lds, U32(skipbits) + (gidx >> 5) * 4u);
+		return has & (((word >> (gidx & 31u)) & 1u) == U32(1u));
+	};
+
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const U32 pos = U32(c * 64u) + lane;
+		LzVal v = lz_value(lds, L.in, B, pos);
+		U32 key = lz_hash(v, B);
+		// lanes of this chunk with the same key
+		U32 cls_lo(0xFFFFFFFFu), cls_hi(0xFFFFFFFFu);
+		for (int b = 0; b < 8; ++b) {
+			Pred bit = ((key >> U32((uint32_t)b)) & 1u) == U32(1u);
+			uint64_t bal = ballot(bit);
+			U32 blo((uint32_t)bal), bhi((uint32_t)(bal >> 32));
+			cls_lo = cls_lo & sel(bit, blo, ~blo);
+			cls_hi = cls_hi & sel(bit, bhi, ~bhi);
+		}
+		// nearest lower lane with the same key, else the table
+		U32 lmask = (U32(1u) << (lane & 31u)) - 1u;
+		U32 below_lo = sel(lane < U32(32u), cls_lo & lmask, cls_lo);
+		U32 below_hi = sel(lane < U32(32u), U32(0u), cls_hi & lmask);
+		Pred has_intra = (below_lo | below_hi) != U32(0u);
+		U32 intra = sel(below_hi != U32(0u), bitlen(below_hi) + 31u, bitlen(below_lo) - 1u);
+		U32 tabv = lds_ld32(lds, U32(tab) + key * 4u);
+		U32 H = sel(has_intra, U32(c * 64u) + intra, tabv);
+		lds_st32(lds, U32(chain) + pos * 4u, H, pred_all(true));
+		// the last lane of each class records its position (the table only matters for later chunks;
+		// positions of groups skipped below are jumped over through the chain)
+		U32 hmask = ~((U32(2u) << (lane & 31u)) - 1u);
+		hmask = sel((lane & 31u) == U32(31u), U32(0u), hmask);
+		U32 above_lo = sel(lane < U32(32u), cls_lo & hmask, U32(0u));
+		U32 above_hi = sel(lane < U32(32u), cls_hi, cls_hi & hmask);
+		lds_st32(lds, U32(tab) + key * 4u, pos, (above_lo | above_hi) == U32(0u));
+		wave_sync();
+
+		// current candidate: follow the chain over groups that were skipped (not hashed)
+		for (;;) {
+			Pred s = skipped(H);
+			if (!any(s))
+				break;
+			H = sel(s, lds_ld32(lds, U32(chain) + sel(s, H, U32(0u)) * 4u), H);
+		}
+
+		// the 8 groups of this chunk, in order
+		for (uint32_t k = 0; k < 8; ++k) {
+			const uint32_t g = c * 8 + k;
+			const uint32_t i = g * 8; // index of the group's first value
+			uint32_t gsize;
+			if (failed == max_failed) { // raw group, not hashed (lz_compress.h:206-211)
+				failed = 0;
+				if (--max_failed == 0)
+					max_failed = 1;
+				lds_or32(lds, U32(skipbits + (g >> 5) * 4u), U32(1u << (g & 31)), lane == U32(0u));
+				wave_sync();
+				gsize = 1 + 8 * B;
+				// later lanes of this chunk that pointed into the skipped group move down the chain
+				for (;;) {
+					Pred s = skipped(H) & (lane >= U32((k + 1) * 8));
+					if (!any(s))
+						break;
+					H = sel(s, lds_ld32(lds, U32(chain) + sel(s, H, U32(0u)) * 4u), H);
+				}
+			}
+			else {
+				Pred ingroup = (lane >> 3) == U32(k);
+				Pred cand = ingroup & (H != U32(LZ_NONE));
+				LzVal hv = lz_value(lds, L.in, B, sel(cand, H, U32(0u)));
+				Pred m = cand & (hv.lo == v.lo) & (hv.hi == v.hi);
+				Pred far = m & ((pos - H) >= U32(128u));
+				uint32_t nm = (uint32_t)__builtin_popcountll(ballot(m));
+				uint32_t nf = (uint32_t)__builtin_popcountll(ballot(far));
+				gsize = 1 + 8 * B - nm * (B - 1) + nf;
+				failed += (nm == 0);
+			}
+			produced += gsize;
+			if (produced > max_size) // (:221-223)
+				return 0;
+			if (!once && i > quarter) { // (:224-229)
+				if ((double)produced > (double)max_size * 0.4)
+					return 0;
+				once = true;
+			}
+		}
+		lds_st32(lds, U32(cur) + pos * 4u, H, pred_all(true));
+		wave_sync();
+	}
+
+	// success: write the stream.  Items of a group follow its flag byte.
+	Lds out = lds + L.out;
+	lds_put_bits(out, U32(base * 8u), U32(BLOCK_LZ), lane == U32(0u));
+	uint32_t run = base + 1; // byte offset of the next chunk's first group flag
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const U32 pos = U32(c * 64u) + lane;
+		LzVal v = lz_value(lds, L.in, B, pos);
+		U32 H = lds_ld32(lds, U32(cur) + pos * 4u);
+		Pred skp = skipped(pos);
+		Pred cand = !skp & (H != U32(LZ_NONE));
+		LzVal hv = lz_value(lds, L.in, B, sel(cand, H, U32(0u)));
+		Pred m = cand & (hv.lo == v.lo) & (hv.hi == v.hi);
+		U32 dist = pos - H;
+		U32 isz = sel(m, sel(dist < U32(128u), U32(1u), U32(2u)), U32(B));
+		U32 incl = wave_incl_scan(isz);
+		uint64_t mb = ballot(m);
+		// byte offset of this item: chunk base + flag bytes of groups up to mine + items before
+		U32 ioff = U32(run) + (lane >> 3) + 1u + (incl - isz);
+		// flag byte (first lane of each group)
+		U32 mlo((uint32_t)mb), mhi((uint32_t)(mb >> 32));
+		U32 flags = (sel(lane < U32(32u), mlo, mhi) >> (lane & 24u)) & 0xFFu;
+		lds_put_bits(out, (ioff - 1u) * 8u, flags, (lane & 7u) == U32(0u));
+		// match: distance on 1 or 2 bytes (write_diff, :140-151)
+		U32 dcode = sel(dist < U32(128u), dist, (dist & 127u) | 128u | ((dist >> 7) << 8));
+		lds_put_bits(out, ioff * 8u, dcode, m);
+		// raw value
+		lds_put_bits(out, ioff * 8u, v.lo, !m);
+		if (B == 8)
+			lds_put_bits(out, (ioff + 4u) * 8u, v.hi, !m);
+		run += 8 + readlane(incl, 63);
+	}
+	wave_sync();
+	return produced;
+}
+
+// Encode the full block at L.in into the output image (zeroed here).  Returns its size in bytes.
+// allow_lz mirrors the reference's capacity condition for the LZ attempt (block_compress.h:1214).
+WV_FN uint32_t encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
+{
+	lds_zero(lds, L.out, out_capacity(T));
+	for (uint32_t g = 0; g < T; g += 4)
+		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16);
+	uint32_t full = plane_offsets(lds, L, T);
+	if (allow_lz && T % 4 == 0 && full * 3 > 256 * T) { // (:1210)
+		uint32_t n = lz_try(lds, L, T, full, 0);
+		if (n)
+			return n + 1;
+		// nothing was written to the image on failure
+	}
+	emit_planes(lds, L, T, 0, 16);
+	return header_bytes(T) + full;
+}
+
+// Encode the `lines` complete rows of a partial block (block_compress_partial, block_compress.h:947-1009).
+// L.in must hold the tail padded to 256*T bytes with its last byte.  The image receives
+// [254][plane types][planes] starting at byte 0; returns the bytes written (the caller appends the
+// remaining raw bytes).
+WV_FN uint32_t encode_partial_lines(Lds lds, const Layout& L, uint32_t T, uint32_t lines)
+{
+	lds_zero(lds, L.out, out_capacity(T));
+	lds_put_bits(lds + L.out, U32(0u), U32(BLOCK_PARTIAL), lane_id() == U32(0u));
+	if (lines == 0) {
+		wave_sync();
+		return 1;
+	}
+	for (uint32_t g = 0; g < T; g += 4)
+		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines);
+	uint32_t full = plane_offsets(lds, L, T);
+	emit_planes(lds, L, T, 1, lines);
+	return 1 + header_bytes(T) + full;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder (block_compress.h:1488-1879, 2088-2175; lz_compress.h:234-277)
+// ------------------------------------------------------------------------------------------------
+
+constexpr uint32_t DEC_ERROR = 0xFFFFFFFFu;
+
+struct DecLayout {
+	uint32_t win;  // window of compressed bytes (+8 slack after the valid bytes)
+	uint32_t img;  // decoded block, element major, 256*T bytes
+	uint32_t total;
+};
+
+// uniform byte / LE16 reads from the window
+WV_FN uint32_t win_u8(Lds lds, uint32_t addr) { return readlane(lds_ld8(lds, U32(addr)), 0); }
+WV_FN uint32_t win_u16(Lds lds, uint32_t addr) { return win_u8(lds, addr) | (win_u8(lds, addr + 1) << 8); }
+
+// store the four bytes of plane j owned by this element lane into the element-major image
+WV_FN void store_plane_word(Lds lds, uint32_t img, uint32_t T, uint32_t j, const U32& w, const Pred& p)
+{
+	U32 a = U32(img + j) + lane_id() * (4u * T);
+	lds_st8(lds, a, byte_of(w, 0), p);
+	lds_st8(lds, a + T, byte_of(w, 1), p);
+	lds_st8(lds, a + 2u * T, byte_of(w, 2), p);
+	lds_st8(lds, a + 3u * T, byte_of(w, 3), p);
+}
+
+// Per byte position k of a lane: out_k = A_k ? out_{k-1} + B_k : B_k  (mod 256).  A is a 4-bit
+// field, Bw four packed bytes.  Returns the four outputs given the carry-in byte `c`.
+WV_FN U32 chain_apply(const U32& A, const U32& Bw, const U32& c)
+{
+	U32 o0 = (byte_of(Bw, 0) + sel((A & 1u) != U32(0u), c, U32(0u))) & 0xFFu;
+	U32 o1 = (byte_of(Bw, 1) + sel((A & 2u) != U32(0u), o0, U32(0u))) & 0xFFu;
+	U32 o2 = (byte_of(Bw, 2) + sel((A & 4u) != U32(0u), o1, U32(0u))) & 0xFFu;
+	U32 o3 = (byte_of(Bw, 3) + sel((A & 8u) != U32(0u), o2, U32(0u))) & 0xFFu;
+	return o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+}
+// compose (apply first f1 = (a1,b1), then f2 = (a2,b2)): packed as a<<8 | b
+WV_FN U32 chain_compose(const U32& f1, const U32& f2)
+{
+	U32 a1 = f1 >> 8, a2 = f2 >> 8;
+	U32 b = sel(a2 != U32(0u), (f1 + f2) & 0xFFu, f2 & 0xFFu);
+	return ((a1 & a2) << 8) | b;
+}
+// exclusive scan of the lane functions; `seg` = scan restarts at lanes where (lane & seg_mask) == 0
+// (seg_mask 63: whole wave, 3: per quad).  Returns the carry-in byte of each lane (0 at a start).
+WV_FN U32 chain_carry(const U32& A, const U32& Bw, uint32_t seg_mask)
+{
+	const U32 lane = lane_id();
+	// the lane's own function: value of its last byte for carry-in 0, and whether the carry goes through
+	U32 last = chain_apply(A, Bw, U32(0u)) >> 24;
+	U32 f = (sel((A & 0xFu) == U32(0xFu), U32(1u), U32(0u)) << 8) | last;
+	const U32 ident(1u << 8);
+	for (uint32_t d = 1; d <= seg_mask; d <<= 1) {
+		U32 prev = shfl_up(f, d, 1u << 8);
+		prev = sel((lane & U32(seg_mask)) >= U32(d), prev, ident);
+		f = chain_compose(prev, f);
+	}
+	U32 ex = shfl_up(f, 1, 1u << 8);
+	ex = sel((lane & U32(seg_mask)) == U32(0u), ident, ex);
+	return ex & 0xFFu; // carry-in for a start value of 0
+}
+
+// expand literals: byte k = flag bit k ? 0 : next literal (literals packed from the low end of lits)
+WV_FN U32 expand_literals(const U32& lits, const U32& f)
+{
+	U32 out(0u), n(0u);
+	for (int k = 0; k < 4; ++k) {
+		Pred lit = ((f >> U32((uint32_t)k)) & 1u) == U32(0u);
+		out = out | sel(lit, ((lits >> (n << 3)) & 0xFFu) << U32(8u * (uint32_t)k), U32(0u));
+		n = n + sel(lit, U32(1u), U32(0u));
+	}
+	return out;
+}
+
+// Decode one NORMAL / NORMAL_RLE plane whose bytes start at window offset `cur` (at most `avail`
+// valid bytes).  Writes rows [0, lines) of plane j into the image.  Returns bytes consumed or DEC_ERROR.
+WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, uint32_t avail, uint32_t lines)
+{
+	const U32 lane = lane_id();
+	Lds win = lds + L.win;
+	const uint32_t nh = (lines + 1) >> 1;
+	// ---- row view: every group of 16 lanes computes the same 16 rows ----
+	const U32 r = lane & 15u;
+	const Pred act = r < U32(lines);
+	uint32_t minslen;
+	U32 hdr, minv;
+	if (type == PLANE_NORMAL) {
+		if (avail < nh + lines) // block_compress.h:1702, 2056
+			return DEC_ERROR;
+		hdr = (lds_ld8(win, U32(cur) + (r >> 1)) >> ((r & 1u) << 2)) & 0xFu;
+		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));
+		U32 e = sel(emit, U32(1u), U32(0u));
+		U32 ex = row_excl_scan(e);
+		minslen = readlane(row_add(e), 0);
+		minv = lds_ld8(win, U32(cur + nh) + sel(emit, ex, U32(0u)));
+	}
+	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins (:1724-1745, 2071-2084)
+		if (avail < 10)
+			return DEC_ERROR;
+		hdr = (lds_ld8(win, U32(cur) + (r >> 1)) >> ((r & 1u) << 2)) & 0xFu;
+		uint32_t mask = win_u16(win, cur + 8);
+		uint32_t nlit = 16 - (uint32_t)__builtin_popcount(mask);
+		if (avail < 10 + nlit)
+			return DEC_ERROR;
+		minslen = 2 + nlit;
+		// min[r] = literal of the last row r' <= r whose mask bit is 0, or 0 when there is none
+		U32 upto = (~U32(mask)) & ((U32(2u) << r) - 1u) & 0xFFFFu;
+		U32 idx = popc(upto);
+		minv = sel(idx == U32(0u), U32(0u), lds_ld8(win, U32(cur + 10) + sel(idx == U32(0u), U32(0u), idx - 1u)));
+	}
+	// row payload sizes; rle rows need their mask, found by walking them in order
+	Pred isrle = act & ((hdr == U32(6u)) | (hdr == U32(7u)));
+	U32 known = sel(act & !isrle, sel(hdr == U32(15u), U32(16u), (hdr & 7u) * 2u), U32(0u));
+	U32 pre = row_excl_scan(known);
+	U32 rmask(0u), extra(0u);
+	const uint32_t base = cur + nh + minslen;
+	uint32_t todo = (uint32_t)(ballot(isrle) & 0xFFFFu);
+	uint32_t rle_total = 0;
+	while (todo) {
+		uint32_t rr = (uint32_t)__builtin_ctz(todo);
+		todo &= todo - 1;
+		uint32_t addr = base + readlane(pre + extra, rr);
+		if (addr + 2 > cur + avail)
+			return DEC_ERROR;
+		uint32_t m = win_u16(win, addr);
+		uint32_t sz = 2 + 16 - (uint32_t)__builtin_popcount(m);
+		rmask = sel(r == U32(rr), U32(m), rmask);
+		extra = extra + sel(r > U32(rr), U32(sz), U32(0u));
+		rle_total += sz;
+	}
+	uint32_t psize = nh + minslen + readlane(row_add(known), 0) + rle_total;
+	if (psize > avail)
+		return DEC_ERROR;
+	U32 poff = U32(base) + pre + extra;
+
+	// ---- element view: lane l owns elements 4l..4l+3, its row is l>>2 ----
+	const U32 row = lane >> 2, q = lane & 3u;
+	U32 info = shfl(hdr | (minv << 8) | (poff << 16), row);
+	U32 emask = shfl(rmask, row);
+	U32 eh = info & 0xFFu, emin = (info >> 8) & 0xFFu, eoff = info >> 16;
+	Pred eact = row < U32(lines);
+	Pred e15 = eh == U32(15u), e7 = eh == U32(7u), e6 = eh == U32(6u);
+	Pred erle = e7 | e6;
+	// bit-packed value bytes
+	U32 bits = eh & 7u;
+	U32 bitoff = (q & 1u) * bits * 4u;
+	U32 px = lds_ld32_unaligned(win, sel(eact, eoff + (q >> 1) * bits + (bitoff >> 3), U32(0u))) >> (bitoff & 7u);
+	U32 vm = (U32(1u) << bits) - 1u;
+	U32 y = (px & vm) | (((px >> bits) & vm) << 8) | (((px >> (bits * 2u)) & vm) << 16) | (((px >> (bits * 3u)) & vm) << 24);
+	U32 packed = bytes_add(y, bytes_splat(emin));
+	// raw row bytes
+	U32 rawv = lds_ld32_unaligned(win, sel(eact & e15, eoff + q * 4u, U32(0u)));
+	// rle rows: flags of this lane and its literals
+	U32 f = (emask >> (q << 2)) & 0xFu;
+	U32 litidx = popc((~emask) & ((U32(1u) << (q << 2)) - 1u) & 0xFFFFu);
+	U32 lits = lds_ld32_unaligned(win, sel(eact & erle, eoff + 2u + litidx, U32(0u)));
+	U32 rlev = expand_literals(lits, f);
+
+	// delta-rle rows first rebuild their deltas: d_k = flag ? d_{k-1} : literal, d_{-1} = 0 per row
+	U32 dv = rlev;
+	if (any(eact & e6)) {
+		U32 A6 = sel(e6, f, U32(0u));
+		U32 cin = chain_carry(A6, rlev, 3);
+		dv = sel(e6, chain_apply(A6, rlev, cin), rlev);
+	}
+	// final chain: absolute rows (A=0), delta rows (A=1), rle rows (A = flags)
+	Pred isdelta = !e15 & !erle & (eh >= U32(8u));
+	U32 A = sel(e6 | isdelta, U32(0xFu), sel(e7, f, U32(0u)));
+	U32 Bw = sel(e15, rawv, sel(e6, dv, sel(e7, rlev, packed)));
+	U32 outw;
+	if (any(A != U32(0u))) {
+		U32 cin = chain_carry(A, Bw, 63);
+		outw = chain_apply(A, Bw, cin);
+	}
+	else
+		outw = Bw;
+	store_plane_word(lds, L.img, T, j, outw, eact);
+	return psize;
+}
+
+// mini-LZ stream -> image.  Returns bytes consumed (after the 253 marker) or DEC_ERROR.
+WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail)
+{
+	const U32 lane = lane_id();
+	Lds win = lds + L.win;
+	const uint32_t B = lz_width(T);
+	const uint32_t count = 256 * T / B;
+	const Pred item = lane < U32(8u);
+	uint32_t p = cur;
+	const uint32_t end = cur + avail;
+	for (uint32_t i = 0; i < count; i += 8) {
+		if (p + 2 > end) // lz_compress.h:242
+			return DEC_ERROR;
+		uint32_t flags = win_u8(win, p);
+		// item sizes: raw = B, match = 1 or 2 (second byte when the first has bit 7 set)
+		Pred m = item & (((U32(flags) >> lane) & 1u) == U32(1u));
+		U32 isz = sel(m, U32(1u), U32(B));
+		U32 off;
+		uint32_t total;
+		for (;;) { // every round fixes at least the first still-mispredicted 2-byte distance
+			U32 incl = sel(item, isz, U32(0u));
+			incl = incl + row_shr(incl, 1, 0);
+			incl = incl + row_shr(incl, 2, 0);
+			incl = incl + row_shr(incl, 4, 0);
+			off = U32(p + 1) + incl - sel(item, isz, U32(0u));
+			total = readlane(incl, 7);
+			if (p + 1 + total > end)
+				return DEC_ERROR;
+			U32 first = lds_ld8(win, sel(m, off, U32(p)));
+			Pred wrong = m & (first > U32(127u)) & (isz == U32(1u));
+			uint64_t wb = ballot(wrong);
+			if (!wb)
+				break;
+			// only the first mispredicted item sits at a trustworthy offset
+			isz = sel(lane == U32((uint32_t)__builtin_ctzll(wb)), U32(2u), isz);
+		}
+		// values: raw items read the window, matches copy an earlier value of the image
+		U32 d0 = lds_ld8(win, sel(m, off, U32(p)));
+		U32 d1 = lds_ld8(win, sel(m, off + 1u, U32(p)));
+		U32 dist = sel(isz == U32(2u), (d0 & 127u) | (d1 << 7), d0);
+		U32 pos = U32(i) + lane;
+		Pred bad = m & ((dist == U32(0u)) | (dist > pos));
+		if (any(bad))
+			return DEC_ERROR;
+		U32 vlo = lds_ld32_unaligned(win, sel(item & !m, off, U32(p)));
+		U32 vhi = B == 8 ? lds_ld32_unaligned(win, sel(item & !m, off + 4u, U32(p))) : U32(0u);
+		// resolve sources inside this group (at most 7 hops), the rest comes from the image
+		U32 src = sel(m, pos - dist, pos); // raw items are their own source
+		for (int hop = 0; hop < 3; ++hop) {
+			Pred ingroup = src >= U32(i);
+			U32 s2 = shfl(src, sel(ingroup, src - U32(i), U32(0u)));
+			src = sel(ingroup, s2, src);
+		}
+		Pred fromimg = item & (src < U32(i));
+		U32 ilo, ihi(0u);
+		if (B == 8)
+			lds_ld64(lds, U32(L.img) + sel(fromimg, src, U32(0u)) * 8u, ilo, ihi);
+		else
+			ilo = lds_ld32(lds, U32(L.img) + sel(fromimg, src, U32(0u)) * 4u);
+		U32 glo = shfl(vlo, sel(fromimg, U32(0u), src - U32(i)));
+		U32 ghi = shfl(vhi, sel(fromimg, U32(0u), src - U32(i)));
+		U32 olo = sel(fromimg, ilo, glo), ohi = sel(fromimg, ihi, ghi);
+		if (B == 8) {
+			lds_st32(lds, U32(L.img) + pos * 8u, olo, item);
+			lds_st32(lds, U32(L.img) + pos * 8u + 4u, ohi, item);
+		}
+		else
+			lds_st32(lds, U32(L.img) + pos * 4u, olo, item);
+		wave_sync();
+		p += 1 + total;
+	}
+	return p - cur;
+}
+
+// Decode `lines` rows (16 = a full block) of the block whose encoding starts at window offset cur.
+// full: a full block (may be COPY / LZ, planes may be RAW / NORMAL_RLE).
+// Returns bytes consumed or DEC_ERROR.
+WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail, uint32_t lines, bool full)
+{
+	const U32 lane = lane_id();
+	Lds win = lds + L.win;
+	const uint32_t hs = header_bytes(T);
+	if (avail <= hs) // src += header_len; src >= end  (block_compress.h:1819-1821)
+		return DEC_ERROR;
+	uint32_t first = win_u8(win, cur);
+	if (full && first == BLOCK_COPY) { // (:1823-1828)
+		if (avail < 1 + 256 * T)
+			return DEC_ERROR;
+		for (uint32_t o = 0; o < 256 * T; o += 256) {
+			U32 v = lds_ld32_unaligned(win, U32(cur + 1 + o) + lane * 4u);
+			lds_st32(lds, U32(L.img + o) + lane * 4u, v, pred_all(true));
+		}
+		wave_sync();
+		return 1 + 256 * T;
+	}
+	if (full && first == BLOCK_LZ) { // (:1829-1835)
+		if (T % 4 != 0)
+			return DEC_ERROR;
+		uint32_t n = lz_decode(lds, L, T, cur + 1, avail - 1);
+		return n == DEC_ERROR ? DEC_ERROR : n + 1;
+	}
+	uint32_t p = cur + hs;
+	const uint32_t end = cur + avail;
+	for (uint32_t j = 0; j < T; ++j) {
+		uint32_t type = (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
+		if (type == PLANE_SAME) { // (:1567-1583)
+			if (p >= end)
+				return DEC_ERROR;
+			U32 v = bytes_splat(lds_ld8(win, U32(p)));
+			store_plane_word(lds, L.img, T, j, v, (lane >> 2) < U32(lines));
+			p += 1;
+		}
+		else if (type == PLANE_RAW && full) { // (:1553-1565)
+			if (end - p < 256)
+				return DEC_ERROR;
+			store_plane_word(lds, L.img, T, j, lds_ld32_unaligned(win, U32(p) + lane * 4u), pred_all(true));
+			p += 256;
+		}
+		else if (type == PLANE_NORMAL || (type == PLANE_NORMAL_RLE && full)) {
+			uint32_t n = decode_plane(lds, L, T, j, type, p, end - p, lines);
+			if (n == DEC_ERROR)
+				return DEC_ERROR;
+			p += n;
+		}
+		else
+			return DEC_ERROR; // (:1854-1855, 1779-1780)
+	}
+	wave_sync();
+	return p - cur;
+}
+
+} // namespace codec

@@ -1,0 +1,921 @@
+// capi.cpp -- host side of libstenos.so: the frozen Stenos C ABI (include/stenos.h) and the
+// device-pointer entry points (include/stenos_hip.h) on top of the gfx950 kernels of kernels.hip.
+//
+// What this file restates from the reference (stenos/internal/stenos.cpp): context and setters
+// (:81-286), frame header and superblock sizing (:115-185, 862-874), the superblock strategy slice for
+// levels 0/1 (:403-450, 606-615, 658-678), decode framing (:1052-1208), stenos_get_info (:1019-1050),
+// the private single-superblock API (:768-842) and the timer wrappers (:1232-1257).  The per-chunk
+// thread dispatcher (:909-1010, tiny_pool.h) is replaced by the GPU grid: `threads` is accepted and ignored.
+//
+// There is no CPU codec here.  If no HIP device is usable every codec call returns
+// STENOS_ERROR_INVALID_INSTRUCTION_SET (the reference's code for "required instruction set missing").
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/stenos_hip.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr size_t kMaxT = 64; // largest bytesoftype of the LDS-resident codec (block_codec.h MAX_T)
+
+inline bool is_err(size_t r) { return r >= STENOS_LAST_ERROR_CODE; }
+
+// ---- zstd through dlopen: only for superblocks < 128 bytes (stenos.cpp:435-437) and for decoding code 2 ----
+typedef size_t (*zstd_compress_fn)(void*, size_t, const void*, size_t, int);
+typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_iserror_fn)(size_t);
+struct Zstd {
+	zstd_compress_fn compress = nullptr;
+	zstd_decompress_fn decompress = nullptr;
+	zstd_iserror_fn is_error = nullptr;
+	bool ok = false;
+	Zstd()
+	{
+		const char* names[] = { "/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", nullptr };
+		void* h = nullptr;
+		for (int i = 0; names[i] && !h; ++i)
+			h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+		if (!h)
+			return;
+		compress = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
+		decompress = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+		is_error = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+		ok = compress && decompress && is_error;
+	}
+};
+Zstd& zstd()
+{
+	static Zstd z;
+	return z;
+}
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	bool ensure(size_t n)
+	{
+		if (n <= cap)
+			return true;
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+		size_t want = (n + 4095) & ~(size_t)4095;
+		if (hipMalloc(&p, want) != hipSuccess) {
+			p = nullptr;
+			return false;
+		}
+		cap = want;
+		return true;
+	}
+	void release()
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+	template <class T>
+	T* as() const
+	{
+		return (T*)p;
+	}
+};
+
+inline void put_le(uint8_t* p, uint64_t v, int n)
+{
+	for (int i = 0; i < n; ++i)
+		p[i] = (uint8_t)(v >> (8 * i));
+}
+inline uint64_t get_le(const uint8_t* p, int n)
+{
+	uint64_t v = 0;
+	for (int i = 0; i < n; ++i)
+		v |= (uint64_t)p[i] << (8 * i);
+	return v;
+}
+
+// stenos.cpp:71-76
+inline size_t base_superblock(size_t block_size)
+{
+	if (block_size > STENOS_BLOCK_SIZE)
+		return block_size;
+	return (STENOS_BLOCK_SIZE / block_size) * block_size;
+}
+
+} // namespace
+
+struct stenos_context_s {
+	// parameters (stenos.cpp:94-106)
+	int level = 1;
+	int threads = 1;
+	uint64_t max_nanoseconds = 0;
+	size_t custom_shift = STENOS_NO_BLOCK_SHIFT;
+
+	// device state
+	bool probed = false, usable = false;
+	DevBuf in, out;                                  // staging for the host-pointer ABI
+	DevBuf slots, bsize, boff, sbcsize, sbcode, sboff; // workspace of the encode pipeline / decode index
+	DevBuf misc;                                     // [0,8) total, [8,12) status, [64,320) override payload
+	uint64_t* h_total = nullptr;                     // pinned: total (8 B) + status (4 B)
+	// last asynchronous job
+	hipStream_t job_stream = nullptr;
+	int job_kind = 0; // 0 none, 1 compress, 2 decompress
+	size_t job_dst_size = 0, job_expected = 0;
+	bool job_host_codes = false; // the last decode met zstd-based superblocks (finished on the host)
+	size_t last_nsb = 0;
+
+	bool device_ready()
+	{
+		if (!probed) {
+			probed = true;
+			int n = 0;
+			usable = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+			if (usable && hipHostMalloc((void**)&h_total, 64, hipHostMallocDefault) != hipSuccess)
+				usable = false;
+		}
+		return usable;
+	}
+	~stenos_context_s()
+	{
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &boff, &sbcsize, &sbcode, &sboff, &misc };
+		for (DevBuf* b : all)
+			b->release();
+		if (h_total)
+			(void)hipHostFree(h_total);
+	}
+};
+
+namespace {
+
+size_t finish_job(stenos_context_s* ctx);
+
+struct FramePlan {
+	size_t sb = 0;          // superblock bytes
+	uint32_t shift = 0;     // frame byte 0 (255 = custom size follows)
+	size_t header = 8;      // frame header bytes
+	uint64_t nsb = 0, nfull = 0;
+	uint32_t tail = 0, bps = 0;
+};
+
+// ctx->prepare + frame geometry (stenos.cpp:115-185, 853-874).  Returns 0 or an error code.
+size_t plan_frame(const stenos_context_s* ctx, size_t T, size_t bytes, int level, FramePlan& f)
+{
+	if (T == 0 || T >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	const size_t bs = T * 256;
+	if (ctx->custom_shift != STENOS_NO_BLOCK_SHIFT) {
+		f.sb = bs << ctx->custom_shift;
+		f.shift = 255;
+		f.header = 12;
+	}
+	else {
+		f.sb = base_superblock(bs);
+		f.shift = 0;
+		if (bytes > f.sb) {
+			f.shift = level ? (uint32_t)(level - 1) / 2 : 0;
+			f.sb <<= f.shift;
+		}
+		f.header = 8;
+	}
+	if (f.sb < bs || f.sb >= STENOS_MAX_BLOCK_BYTES)
+		return STENOS_ERROR_INVALID_PARAMETER;
+	f.nsb = bytes / f.sb + (bytes % f.sb ? 1 : 0);
+	f.nfull = bytes / bs;
+	f.tail = (uint32_t)(bytes % bs);
+	f.bps = (uint32_t)(f.sb / bs);
+	return 0;
+}
+
+// What this build cannot do yet is refused loudly instead of being routed to a CPU path.
+size_t check_supported(const stenos_context_s* ctx, size_t T, int level)
+{
+	if (ctx->max_nanoseconds) // time-limited mode: wall-clock dependent output
+		return STENOS_ERROR_INVALID_PARAMETER;
+	if (level > 1) // levels >= 2 need the lz4-dry estimator + zstd orchestration
+		return STENOS_ERROR_INVALID_PARAMETER;
+	if (level == 1 && (T == 1 || T > kMaxT))
+		return STENOS_ERROR_INVALID_PARAMETER;
+	return 0;
+}
+
+// Enqueue the compression of `bytes` device bytes into a frame (or, with frame_header == false, into
+// the bare superblock stream used by the private API).  Nothing is waited for except, for a final
+// superblock shorter than 128 bytes, the copy of those bytes to the host.
+size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, size_t bytes, uint8_t* d_dst, size_t dst_size, int level,
+			const FramePlan& f, bool frame_header, hipStream_t stream)
+{
+	const size_t header = frame_header ? f.header : 0;
+	const uint64_t nblocks = f.nfull + (f.tail ? 1 : 0);
+	const uint32_t stride = stenos_k_slot_stride((uint32_t)T);
+	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) || !ctx->sbcsize.ensure((f.nsb + 1) * 4) ||
+	    !ctx->sbcode.ensure(f.nsb + 1) || !ctx->sboff.ensure((f.nsb + 2) * 8) || !ctx->misc.ensure(4096))
+		return STENOS_ERROR_ALLOC;
+	if (level >= 1 && !ctx->slots.ensure((nblocks + 1) * (size_t)stride))
+		return STENOS_ERROR_ALLOC;
+
+	uint32_t override_code = 0, override_size = 0;
+	const size_t last_bytes = bytes - (f.nsb - 1) * f.sb;
+	if (level >= 1 && last_bytes < 128) { // small input: direct zstd, zstd level 1 (stenos.cpp:435-437, zstd_wrapper.h:49-56)
+		if (!zstd().ok)
+			return STENOS_ERROR_ZSTD_INTERNAL;
+		uint8_t raw[128], comp[512];
+		if (hipMemcpyAsync(raw, d_src + (bytes - last_bytes), last_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		    hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		size_t r = zstd().compress(comp, sizeof(comp), raw, last_bytes, 1);
+		const uint8_t* payload = comp;
+		if (zstd().is_error(r) || r > last_bytes) { // -> MEMCPY (stenos.cpp:668-669)
+			override_code = 6;
+			override_size = (uint32_t)last_bytes;
+			payload = raw;
+		}
+		else {
+			override_code = 2;
+			override_size = (uint32_t)r;
+		}
+		if (hipMemcpyAsync(ctx->misc.as<uint8_t>() + 64, payload, override_size, hipMemcpyHostToDevice, stream) != hipSuccess ||
+		    hipStreamSynchronize(stream) != hipSuccess) // payload lives on this stack frame
+			return STENOS_ERROR_UNDEFINED;
+	}
+
+	if (level >= 1) {
+		if (stenos_k_launch_encode(d_src, f.nfull, f.tail, (uint32_t)T, ctx->slots.as<uint8_t>(), ctx->bsize.as<uint32_t>(), stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+	}
+	SuperblockPlanArgs pa;
+	pa.bsize = ctx->bsize.as<uint32_t>();
+	pa.boff = ctx->boff.as<uint32_t>();
+	pa.sb_csize = ctx->sbcsize.as<uint32_t>();
+	pa.sb_code = ctx->sbcode.as<uint8_t>();
+	pa.nfull = f.nfull;
+	pa.nsb = f.nsb;
+	pa.total_bytes = bytes;
+	pa.tail_bytes = f.tail;
+	pa.bps = f.bps;
+	pa.sb_bytes = (uint32_t)f.sb;
+	pa.override_code = override_code;
+	pa.override_size = override_size;
+	pa.force_copy = level == 0 ? 1u : 0u;
+	if (stenos_k_launch_plan(pa, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	uint64_t* d_total = ctx->misc.as<uint64_t>();
+	if (stenos_k_launch_scan(ctx->sbcsize.as<uint32_t>(), f.nsb, header, ctx->sboff.as<uint64_t>(), d_total, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	PackArgs ka;
+	ka.src = d_src;
+	ka.dst = d_dst;
+	ka.dst_size = dst_size;
+	ka.slots = ctx->slots.as<uint8_t>();
+	ka.bsize = ctx->bsize.as<uint32_t>();
+	ka.boff = ctx->boff.as<uint32_t>();
+	ka.sb_csize = ctx->sbcsize.as<uint32_t>();
+	ka.sb_code = ctx->sbcode.as<uint8_t>();
+	ka.sb_off = ctx->sboff.as<uint64_t>();
+	ka.total = d_total;
+	ka.override_payload = ctx->misc.as<uint8_t>() + 64;
+	ka.nfull = f.nfull;
+	ka.nsb = f.nsb;
+	ka.total_bytes = bytes;
+	ka.tail_bytes = f.tail;
+	ka.bps = f.bps;
+	ka.sb_bytes = (uint32_t)f.sb;
+	ka.slot_stride = stride;
+	ka.T = (uint32_t)T;
+	ka.shift_byte = frame_header ? f.shift : 0xFFFFFFFFu;
+	ka.override_code = override_code;
+	if (stenos_k_launch_pack(ka, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	if (hipMemcpyAsync(ctx->h_total, d_total, 8, hipMemcpyDeviceToHost, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	ctx->last_nsb = f.nsb;
+	return 0;
+}
+
+size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_t bytes, void* d_dst, size_t dst_size, hipStream_t stream, bool wait)
+{
+	if (!ctx->device_ready())
+		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	const int level = ctx->level;
+	FramePlan f;
+	size_t e = plan_frame(ctx, T, bytes, level, f);
+	if (is_err(e))
+		return e;
+	e = check_supported(ctx, T, level);
+	if (is_err(e))
+		return e;
+	if (dst_size < f.header) // stenos.cpp:862-863, 870-871
+		return STENOS_ERROR_DST_OVERFLOW;
+	ctx->job_kind = 0;
+	if (bytes == 0) { // stenos.cpp:876-878
+		uint8_t h[12];
+		h[0] = (uint8_t)f.shift;
+		put_le(h + 1, 0, 7);
+		put_le(h + 8, f.sb, 4);
+		if (hipMemcpyAsync(d_dst, h, f.header, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		ctx->last_nsb = 0;
+		ctx->h_total[0] = f.header;
+		ctx->job_kind = 1;
+		ctx->job_stream = stream;
+		ctx->job_dst_size = dst_size;
+		return f.header;
+	}
+	e = enqueue_compress(ctx, (const uint8_t*)d_src, T, bytes, (uint8_t*)d_dst, dst_size, level, f, true, stream);
+	if (is_err(e))
+		return e;
+	ctx->job_kind = 1;
+	ctx->job_stream = stream;
+	ctx->job_dst_size = dst_size;
+	return wait ? finish_job(ctx) : 0;
+}
+
+struct FrameInfo {
+	uint64_t total = 0;
+	size_t sb = 0, header = 0;
+	uint64_t nsb = 0;
+};
+// frame header checks of stenos_decompress_generic (stenos.cpp:1066-1116); returns 0 or an error code
+size_t parse_frame(const uint8_t* h, size_t have, size_t T, size_t dst_size, FrameInfo& fi)
+{
+	if (T == 0 || T >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	if (have < 8)
+		return STENOS_ERROR_SRC_OVERFLOW;
+	const unsigned shift = h[0];
+	if (shift > 4 && shift != 255)
+		return STENOS_ERROR_INVALID_INPUT;
+	fi.total = get_le(h + 1, 7);
+	if (fi.total > dst_size)
+		return STENOS_ERROR_DST_OVERFLOW;
+	fi.header = 8;
+	if (fi.total == 0)
+		return 0;
+	if (shift == 255) {
+		if (have < 12)
+			return STENOS_ERROR_SRC_OVERFLOW;
+		fi.sb = (size_t)get_le(h + 8, 4);
+		fi.header = 12;
+		if (fi.sb == 0)
+			return STENOS_ERROR_INVALID_INPUT;
+	}
+	else
+		fi.sb = base_superblock(T * 256) << shift;
+	// Unlike the reference (stenos.cpp:1115-1116, 1131) the last superblock of a frame whose size is an
+	// exact multiple of the superblock size is decoded with its full size instead of 0 bytes.
+	fi.nsb = fi.total / fi.sb + (fi.total % fi.sb ? 1 : 0);
+	return 0;
+}
+
+// Finish superblocks that carry zstd-only payloads (code 2) on the host; codes 3-5 are not handled yet.
+// h_index: nsb + 1 header offsets on the host; frame/dst are device pointers.
+size_t finish_host_codes(const uint8_t* d_frame, size_t size, const uint64_t* h_index, const FrameInfo& fi, uint8_t* d_dst, hipStream_t stream)
+{
+	std::vector<uint8_t> comp, raw;
+	for (uint64_t s = 0; s < fi.nsb; ++s) {
+		uint8_t hd[4];
+		if (h_index[s] + 4 > size)
+			return STENOS_ERROR_SRC_OVERFLOW;
+		if (hipMemcpyAsync(hd, d_frame + h_index[s], 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		if (hd[0] == 1 || hd[0] == 6)
+			continue;
+		if (hd[0] != 2)
+			return STENOS_ERROR_INVALID_INPUT;
+		if (!zstd().ok)
+			return STENOS_ERROR_ZSTD_INTERNAL;
+		const size_t csize = (size_t)get_le(hd + 1, 3);
+		const uint64_t begin = s * (uint64_t)fi.sb;
+		const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
+		if (h_index[s] + 4 + csize > size)
+			return STENOS_ERROR_INVALID_INPUT;
+		comp.resize(csize);
+		raw.resize(dsize);
+		if (hipMemcpyAsync(comp.data(), d_frame + h_index[s] + 4, csize, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		    hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		size_t r = zstd().decompress(raw.data(), dsize, comp.data(), csize);
+		if (zstd().is_error(r)) // stenos.cpp:696-698
+			return STENOS_ERROR_INVALID_INPUT;
+		if (hipMemcpyAsync(d_dst + begin, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+	}
+	return 0;
+}
+
+size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_t size, void* d_dst, size_t dst_size, const uint64_t* d_index,
+			 const uint64_t* h_index, hipStream_t stream, bool wait)
+{
+	if (!ctx->device_ready())
+		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	uint8_t h[12] = { 0 };
+	const size_t have = size < 12 ? size : 12;
+	if (have && (hipMemcpyAsync(h, d_src, have, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
+		return STENOS_ERROR_UNDEFINED;
+	FrameInfo fi;
+	size_t e = parse_frame(h, have, T, dst_size, fi);
+	if (is_err(e))
+		return e;
+	ctx->job_kind = 0;
+	if (fi.total == 0)
+		return 0;
+	if (T > kMaxT)
+		return STENOS_ERROR_INVALID_PARAMETER;
+	if (!ctx->misc.ensure(4096) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
+		return STENOS_ERROR_ALLOC;
+	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
+	if (hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	if (!d_index) {
+		d_index = ctx->sboff.as<uint64_t>();
+		if (stenos_k_launch_walk((const uint8_t*)d_src, size, fi.header, fi.nsb, ctx->sboff.as<uint64_t>(), d_status, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+	}
+	DecodeArgs a;
+	a.frame = (const uint8_t*)d_src;
+	a.size = size;
+	a.sb_off = d_index;
+	a.dst = (uint8_t*)d_dst;
+	a.total_bytes = fi.total;
+	a.nsb = fi.nsb;
+	a.sb_bytes = (uint32_t)fi.sb;
+	a.T = (uint32_t)T;
+	a.status = d_status;
+	if (stenos_k_launch_decode(a, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	if (hipMemcpyAsync((uint8_t*)ctx->h_total + 8, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	ctx->job_kind = 2;
+	ctx->job_stream = stream;
+	ctx->job_expected = (size_t)fi.total;
+	if (!wait)
+		return 0;
+	size_t r = finish_job(ctx);
+	if (!is_err(r) && ctx->job_host_codes) { // zstd-based superblocks present
+		std::vector<uint64_t> idx;
+		if (!h_index) {
+			idx.resize(fi.nsb + 1);
+			if (hipMemcpy(idx.data(), d_index, (fi.nsb + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			h_index = idx.data();
+		}
+		e = finish_host_codes((const uint8_t*)d_src, size, h_index, fi, (uint8_t*)d_dst, stream);
+		return is_err(e) ? e : (size_t)fi.total;
+	}
+	return r;
+}
+
+} // namespace
+
+// =====================================================================================================
+// exported C ABI
+// =====================================================================================================
+extern "C" {
+
+stenos_context* stenos_make_context(void)
+{
+	void* m = malloc(sizeof(stenos_context_s));
+	return m ? new (m) stenos_context_s() : nullptr;
+}
+void stenos_destroy_context(stenos_context* ctx)
+{
+	if (ctx) {
+		ctx->~stenos_context_s();
+		free(ctx);
+	}
+}
+void stenos_reset_context(stenos_context* ctx) // stenos.cpp:245-252 (the custom block size is kept, as there)
+{
+	if (ctx) {
+		ctx->level = 1;
+		ctx->threads = 1;
+		ctx->max_nanoseconds = 0;
+	}
+}
+size_t stenos_set_level(stenos_context* ctx, int level)
+{
+	ctx->level = level > 9 ? 9 : (level < 0 ? 0 : level);
+	return 0;
+}
+size_t stenos_set_threads(stenos_context* ctx, int threads)
+{
+	ctx->threads = threads < 1 ? 1 : threads;
+	return 0;
+}
+size_t stenos_set_max_nanoseconds(stenos_context* ctx, uint64_t nanoseconds)
+{
+	ctx->max_nanoseconds = nanoseconds;
+	return 0;
+}
+size_t stenos_set_block_size(stenos_context* ctx, size_t blocksize_shift)
+{
+	if (blocksize_shift >= 16 && blocksize_shift != STENOS_NO_BLOCK_SHIFT)
+		return STENOS_ERROR_INVALID_PARAMETER;
+	ctx->custom_shift = blocksize_shift;
+	return 0;
+}
+size_t stenos_memory_footprint(stenos_context* ctx)
+{
+	// host bytes of the context; device buffers are reported by stenos_hip_workspace_bytes()
+	(void)ctx;
+	return sizeof(stenos_context_s);
+}
+int stenos_has_error(size_t r) { return r >= STENOS_LAST_ERROR_CODE; }
+size_t stenos_bound(size_t bytes) { return stenos::compress_bound(bytes); }
+
+size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t bytesoftype, size_t bytes, void* dst, size_t dst_size)
+{
+	FramePlan f;
+	size_t e = plan_frame(ctx, bytesoftype, bytes, ctx->level, f);
+	if (is_err(e))
+		return e;
+	e = check_supported(ctx, bytesoftype, ctx->level);
+	if (is_err(e))
+		return e;
+	if (dst_size < f.header)
+		return STENOS_ERROR_DST_OVERFLOW;
+	uint8_t* out = (uint8_t*)dst;
+	if (bytes == 0 || ctx->level == 0) {
+		// header only, or plain copies (stenos.cpp:431-433, 363-374): no codec involved, done in place
+		const size_t need = f.header + f.nsb * 4 + bytes;
+		if (dst_size < need)
+			return STENOS_ERROR_DST_OVERFLOW;
+		out[0] = (uint8_t)f.shift;
+		put_le(out + 1, bytes, 7);
+		if (f.header == 12)
+			put_le(out + 8, f.sb, 4);
+		size_t off = f.header;
+		for (uint64_t s = 0; s < f.nsb; ++s) {
+			size_t n = (size_t)((bytes - s * f.sb) < f.sb ? (bytes - s * f.sb) : f.sb);
+			out[off] = 6;
+			put_le(out + off + 1, n, 3);
+			memcpy(out + off + 4, (const uint8_t*)src + s * f.sb, n);
+			off += 4 + n;
+		}
+		return off;
+	}
+	if (!ctx->device_ready())
+		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	const size_t bound = stenos_bound(bytes);
+	if (!ctx->in.ensure(bytes + 64) || !ctx->out.ensure(bound + 64))
+		return STENOS_ERROR_ALLOC;
+	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	size_t r = compress_device(ctx, ctx->in.p, bytesoftype, bytes, ctx->out.p, bound, nullptr, true);
+	if (is_err(r))
+		return r;
+	if (r > dst_size) // the caller's buffer is too small: report, never write past it
+		return STENOS_ERROR_DST_OVERFLOW;
+	if (hipMemcpy(dst, ctx->out.p, r, hipMemcpyDeviceToHost) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	return r;
+}
+
+size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t bytesoftype, size_t size, void* dst, size_t dst_size)
+{
+	const uint8_t* in = (const uint8_t*)src;
+	FrameInfo fi;
+	size_t e = parse_frame(in, size, bytesoftype, dst_size, fi);
+	if (is_err(e))
+		return e;
+	if (fi.total == 0)
+		return 0;
+	// walk the superblock chain on the host (stenos.cpp:1124-1143): cheap here, serial on a GPU
+	std::vector<uint64_t> index(fi.nsb + 1);
+	uint64_t p = fi.header;
+	bool gpu_codes = false, host_codes = false;
+	for (uint64_t s = 0; s < fi.nsb; ++s) {
+		if (p + 4 > size)
+			return STENOS_ERROR_SRC_OVERFLOW;
+		index[s] = p;
+		const unsigned code = in[p];
+		const size_t csize = (size_t)get_le(in + p + 1, 3);
+		if (p + 4 + csize > size)
+			return STENOS_ERROR_INVALID_INPUT;
+		if (code == 1)
+			gpu_codes = true;
+		else if (code >= 2 && code <= 5)
+			host_codes = true;
+		else if (code != 6)
+			return STENOS_ERROR_INVALID_INPUT;
+		p += 4 + csize;
+	}
+	index[fi.nsb] = p;
+	uint8_t* out = (uint8_t*)dst;
+	if (!gpu_codes) { // copies and zstd-only superblocks: nothing for the GPU to do
+		for (uint64_t s = 0; s < fi.nsb; ++s) {
+			const uint64_t begin = s * (uint64_t)fi.sb;
+			const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
+			const unsigned code = in[index[s]];
+			const size_t csize = (size_t)get_le(in + index[s] + 1, 3);
+			if (code == 6) {
+				if (csize != dsize)
+					return STENOS_ERROR_INVALID_INPUT;
+				memcpy(out + begin, in + index[s] + 4, csize);
+			}
+			else if (code == 2) {
+				if (!zstd().ok)
+					return STENOS_ERROR_ZSTD_INTERNAL;
+				size_t r = zstd().decompress(out + begin, dsize, in + index[s] + 4, csize);
+				if (zstd().is_error(r))
+					return STENOS_ERROR_INVALID_INPUT;
+			}
+			else
+				return STENOS_ERROR_INVALID_INPUT; // codes 3-5: levels >= 2, not handled by this build yet
+		}
+		return (size_t)fi.total;
+	}
+	if (!ctx->device_ready())
+		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	if (!ctx->in.ensure(size + 64) || !ctx->out.ensure((size_t)fi.total + 64) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
+		return STENOS_ERROR_ALLOC;
+	if (hipMemcpy(ctx->in.p, src, size, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(ctx->sboff.p, index.data(), (fi.nsb + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	(void)host_codes;
+	size_t r = decompress_device(ctx, ctx->in.p, bytesoftype, size, ctx->out.p, (size_t)fi.total, ctx->sboff.as<uint64_t>(), index.data(), nullptr, true);
+	if (is_err(r))
+		return r;
+	if (hipMemcpy(dst, ctx->out.p, (size_t)fi.total, hipMemcpyDeviceToHost) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	return (size_t)fi.total;
+}
+
+size_t stenos_compress(const void* src, size_t bytesoftype, size_t bytes, void* dst, size_t dst_size, int level)
+{
+	stenos_context_s ctx; // temporary context (stenos.cpp:1210-1218)
+	ctx.level = level > 9 ? 9 : (level < 0 ? 0 : level);
+	return stenos_compress_generic(&ctx, src, bytesoftype, bytes, dst, dst_size);
+}
+size_t stenos_decompress(const void* src, size_t bytesoftype, size_t bytes, void* dst, size_t dst_size)
+{
+	stenos_context_s ctx;
+	return stenos_decompress_generic(&ctx, src, bytesoftype, bytes, dst, dst_size);
+}
+
+size_t stenos_get_info(const void* src, size_t bytesoftype, size_t bytes, stenos_info* info) // stenos.cpp:1019-1050
+{
+	const uint8_t* in = (const uint8_t*)src;
+	if (bytes < 8)
+		return STENOS_ERROR_SRC_OVERFLOW;
+	const unsigned shift = in[0];
+	if (shift > 4 && shift != 255)
+		return STENOS_ERROR_INVALID_INPUT;
+	info->decompressed_size = (size_t)get_le(in + 1, 7);
+	if (shift == 255) {
+		if (bytes < 12)
+			return STENOS_ERROR_SRC_OVERFLOW;
+		info->superblock_size = (size_t)get_le(in + 8, 4);
+		return 12;
+	}
+	info->superblock_size = base_superblock(bytesoftype * 256) << shift;
+	return 8;
+}
+
+// ---- timer (stenos.cpp:1232-1257, timer.hpp:104-133) ----
+struct stenos_timer_s {
+	struct timespec t0;
+};
+stenos_timer* stenos_make_timer(void)
+{
+	stenos_timer* t = (stenos_timer*)malloc(sizeof(stenos_timer));
+	if (t)
+		clock_gettime(CLOCK_MONOTONIC, &t->t0);
+	return t;
+}
+void stenos_destroy_timer(stenos_timer* timer) { free(timer); }
+void stenos_tick(stenos_timer* timer) { clock_gettime(CLOCK_MONOTONIC, &timer->t0); }
+uint64_t stenos_tock(stenos_timer* timer)
+{
+	struct timespec t1;
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (uint64_t)(t1.tv_sec - timer->t0.tv_sec) * 1000000000ull + (uint64_t)t1.tv_nsec - (uint64_t)timer->t0.tv_nsec;
+}
+
+// ---- private single-superblock API used by stenos::cvector (stenos.cpp:768-842) ----
+size_t stenos_private_compress_block(stenos_context* ctx, const void* src, size_t bytesoftype, size_t super_block_size, size_t bytes, void* dst,
+				     size_t dst_size)
+{
+	if (dst_size < 4) // stenos.cpp:427-429
+		return STENOS_ERROR_DST_OVERFLOW;
+	if (bytesoftype == 0 || bytesoftype >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	uint8_t* out = (uint8_t*)dst;
+	if (bytes == 0 || ctx->level == 0) { // MEMCPY (stenos.cpp:431-433)
+		if (dst_size < bytes + 4)
+			return STENOS_ERROR_DST_OVERFLOW;
+		out[0] = 6;
+		put_le(out + 1, bytes, 3);
+		memcpy(out + 4, src, bytes);
+		return bytes + 4;
+	}
+	size_t e = check_supported(ctx, bytesoftype, ctx->level);
+	if (is_err(e))
+		return e;
+	if (!ctx->device_ready())
+		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	if (bytes > super_block_size || super_block_size >= STENOS_MAX_BLOCK_BYTES)
+		return STENOS_ERROR_INVALID_PARAMETER;
+	FramePlan f;
+	f.sb = super_block_size;
+	f.nsb = 1;
+	f.nfull = bytes / (bytesoftype * 256);
+	f.tail = (uint32_t)(bytes % (bytesoftype * 256));
+	f.bps = (uint32_t)(super_block_size / (bytesoftype * 256));
+	if (f.bps == 0)
+		return STENOS_ERROR_INVALID_PARAMETER;
+	if (!ctx->in.ensure(bytes + 64) || !ctx->out.ensure(bytes + 64))
+		return STENOS_ERROR_ALLOC;
+	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	e = enqueue_compress(ctx, ctx->in.as<uint8_t>(), bytesoftype, bytes, ctx->out.as<uint8_t>(), bytes + 4, ctx->level, f, false, nullptr);
+	if (is_err(e))
+		return e;
+	ctx->job_kind = 1;
+	ctx->job_stream = nullptr;
+	ctx->job_dst_size = bytes + 4;
+	size_t r = finish_job(ctx);
+	if (is_err(r))
+		return r;
+	if (r > dst_size)
+		return STENOS_ERROR_DST_OVERFLOW;
+	if (hipMemcpy(dst, ctx->out.p, r, hipMemcpyDeviceToHost) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	return r;
+}
+
+size_t stenos_private_decompress_block(stenos_context* ctx, const void* src, size_t bytesoftype, size_t super_block_size, size_t bytes, void* dst,
+				       size_t dst_size)
+{
+	(void)super_block_size;
+	const uint8_t* in = (const uint8_t*)src;
+	if (bytes < 4) // stenos.cpp:792-793
+		return STENOS_ERROR_SRC_OVERFLOW;
+	if (bytesoftype == 0 || bytesoftype >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	const unsigned code = in[0];
+	const size_t csize = (size_t)get_le(in + 1, 3);
+	if (4 + csize > bytes)
+		return STENOS_ERROR_INVALID_INPUT;
+	if (code == 6) {
+		if (csize != dst_size)
+			return STENOS_ERROR_INVALID_INPUT;
+		memcpy(dst, in + 4, csize);
+		return dst_size;
+	}
+	if (code == 2) {
+		if (!zstd().ok)
+			return STENOS_ERROR_ZSTD_INTERNAL;
+		size_t r = zstd().decompress(dst, dst_size, in + 4, csize);
+		return zstd().is_error(r) ? STENOS_ERROR_INVALID_INPUT : dst_size;
+	}
+	if (code != 1 || bytesoftype > kMaxT)
+		return STENOS_ERROR_INVALID_INPUT;
+	if (dst_size == 0)
+		return 0;
+	if (!ctx->device_ready())
+		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	if (!ctx->in.ensure(4 + csize + 64) || !ctx->out.ensure(dst_size + 64) || !ctx->sboff.ensure(32) || !ctx->misc.ensure(4096))
+		return STENOS_ERROR_ALLOC;
+	const uint64_t index[2] = { 0, 4 + csize };
+	if (hipMemcpy(ctx->in.p, src, 4 + csize, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(ctx->sboff.p, index, sizeof(index), hipMemcpyHostToDevice) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
+	if (hipMemsetAsync(d_status, 0, 4, nullptr) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	DecodeArgs a;
+	a.frame = ctx->in.as<uint8_t>();
+	a.size = 4 + csize;
+	a.sb_off = ctx->sboff.as<uint64_t>();
+	a.dst = ctx->out.as<uint8_t>();
+	a.total_bytes = dst_size;
+	a.nsb = 1;
+	a.sb_bytes = (uint32_t)dst_size;
+	a.T = (uint32_t)bytesoftype;
+	a.status = d_status;
+	if (stenos_k_launch_decode(a, nullptr) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	uint32_t status = 0;
+	if (hipMemcpy(&status, d_status, 4, hipMemcpyDeviceToHost) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	if (status)
+		return STENOS_ERROR_INVALID_INPUT;
+	if (hipMemcpy(dst, ctx->out.p, dst_size, hipMemcpyDeviceToHost) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	return dst_size;
+}
+
+size_t stenos_private_block_size(const void* src, size_t src_size)
+{
+	if (src_size < 4)
+		return STENOS_ERROR_SRC_OVERFLOW;
+	return (size_t)get_le((const uint8_t*)src + 1, 3) + 4;
+}
+size_t stenos_private_block_csize(const void* src)
+{
+	if (!src)
+		return 0;
+	return (size_t)get_le((const uint8_t*)src + 1, 3) + 4;
+}
+size_t stenos_private_create_compression_header(size_t decompressed_size, size_t super_block_size, void* dst, size_t dst_size)
+{
+	if (dst_size < 12)
+		return STENOS_ERROR_DST_OVERFLOW;
+	uint8_t* out = (uint8_t*)dst;
+	out[0] = 255;
+	put_le(out + 1, decompressed_size, 7);
+	put_le(out + 8, super_block_size, 4);
+	return 12;
+}
+
+// =====================================================================================================
+// device-pointer entry points (include/stenos_hip.h)
+// =====================================================================================================
+
+int stenos_hip_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes)
+{
+	if (bytesoftype == 0 || bytesoftype > kMaxT)
+		return 0;
+	const size_t bs = bytesoftype * 256;
+	const size_t nblocks = bytes / bs + 2;
+	const size_t nsb = bytes / base_superblock(bs) + 2;
+	return nblocks * (stenos_k_slot_stride((uint32_t)bytesoftype) + 8) + nsb * 13 + 4096;
+}
+
+size_t stenos_hip_compress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream)
+{
+	return compress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, (hipStream_t)stream, true);
+}
+size_t stenos_hip_compress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream)
+{
+	return compress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, (hipStream_t)stream, false);
+}
+
+size_t stenos_hip_finish(stenos_context* ctx)
+{
+	size_t r = finish_job(ctx);
+	// frames with zstd-based superblocks need the synchronous call, which finishes them on the host
+	return (!is_err(r) && ctx->job_host_codes) ? STENOS_ERROR_ZSTD_INTERNAL : r;
+}
+
+} // extern "C"
+
+namespace {
+size_t finish_job(stenos_context_s* ctx)
+{
+	ctx->job_host_codes = false;
+	if (!ctx->job_kind)
+		return STENOS_ERROR_INVALID_PARAMETER;
+	if (hipStreamSynchronize(ctx->job_stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	const int kind = ctx->job_kind;
+	ctx->job_kind = 0;
+	if (kind == 1) {
+		const uint64_t total = ctx->h_total[0];
+		return total > ctx->job_dst_size ? STENOS_ERROR_DST_OVERFLOW : (size_t)total;
+	}
+	const uint32_t status = *(const uint32_t*)((const uint8_t*)ctx->h_total + 8);
+	if (status & DECODE_STATUS_TRUNCATED)
+		return STENOS_ERROR_SRC_OVERFLOW;
+	if (status & DECODE_STATUS_INVALID)
+		return STENOS_ERROR_INVALID_INPUT;
+	ctx->job_host_codes = (status & DECODE_STATUS_HOST_CODES) != 0;
+	return ctx->job_expected;
+}
+} // namespace
+
+extern "C" {
+
+const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb)
+{
+	if (nsb)
+		*nsb = ctx->last_nsb;
+	return ctx->sboff.as<uint64_t>();
+}
+
+size_t stenos_hip_decompress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size,
+			     const uint64_t* d_index, void* stream)
+{
+	return decompress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, d_index, nullptr, (hipStream_t)stream, true);
+}
+size_t stenos_hip_decompress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size,
+				   const uint64_t* d_index, void* stream)
+{
+	return decompress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, d_index, nullptr, (hipStream_t)stream, false);
+}
+
+} // extern "C"

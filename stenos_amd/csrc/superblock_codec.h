@@ -1,0 +1,225 @@
+// superblock_codec.h -- what one wavefront does around block_codec.h: moving blocks between HBM and
+// its LDS scratch, the partial (tail) block, walking the blocks of one superblock on decode, and the
+// byte-granular copies that assemble the frame.  Written in the wavevec.h vocabulary, so the host
+// emulation in tests/emul exercises the same code the gfx950 kernels run.
+//
+// Reference behaviour restated here: block_compress / block_decompress outer loops
+// (stenos/internal/block_compress.h:1152-1298, 1817-1878) and block_compress_partial (:947-1020).
+#pragma once
+#include "block_codec.h"
+
+namespace codec {
+
+// ---- HBM <-> LDS copies by one wave ---------------------------------------------------------------
+
+// g must be 16-byte aligned; never reads past g + n
+WV_FN void copy_g2l(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t full = n & ~15u;
+	for (uint32_t o = 0; o < full; o += 1024) {
+		U32 off = U32(o) + lane * 16u;
+		Pred p = off < U32(full);
+		lds_st128(lds, U32(ldsoff) + off, gld128(g, off, p), p);
+	}
+	Pred t = lane < U32(n - full);
+	lds_st8(lds, U32(ldsoff + full) + lane, gld8(g, U32(full) + lane, t), t);
+}
+// any alignment of g
+WV_FN void copy_g2l_bytes(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
+{
+	const U32 lane = lane_id();
+	for (uint32_t o = 0; o < n; o += 64) {
+		Pred p = (U32(o) + lane) < U32(n);
+		lds_st8(lds, U32(ldsoff + o) + lane, gld8(g, U32(o) + lane, p), p);
+	}
+}
+WV_FN void load_block(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
+{
+	if ((((uintptr_t)g) & 15u) == 0)
+		copy_g2l(lds, ldsoff, g, n);
+	else
+		copy_g2l_bytes(lds, ldsoff, g, n);
+}
+// LDS image -> HBM, never writes past g + n
+WV_FN void store_block(uint8_t* g, Lds lds, uint32_t ldsoff, uint32_t n)
+{
+	const U32 lane = lane_id();
+	if ((((uintptr_t)g) & 15u) == 0) {
+		const uint32_t full = n & ~15u;
+		for (uint32_t o = 0; o < full; o += 1024) {
+			U32 off = U32(o) + lane * 16u;
+			Pred p = off < U32(full);
+			gst128(g, off, lds_ld128(lds, U32(ldsoff) + sel(p, off, U32(0u))), p);
+		}
+		Pred t = lane < U32(n - full);
+		gst8(g, U32(full) + lane, lds_ld8(lds, U32(ldsoff + full) + sel(t, lane, U32(0u))), t);
+	}
+	else
+		for (uint32_t o = 0; o < n; o += 64) {
+			Pred p = (U32(o) + lane) < U32(n);
+			gst8(g, U32(o) + lane, lds_ld8(lds, U32(ldsoff + o) + sel(p, lane, U32(0u))), p);
+		}
+}
+
+// HBM -> HBM copy of n bytes by one wave; any alignment on both sides.  Source words are read from
+// the 4-byte aligned addresses that contain the bytes (never below src & ~3, never at or past the
+// aligned word that holds the last byte + 1), destination words are written aligned.
+WV_FN void copy_g2g(uint8_t* dst, const uint8_t* src, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u); // bytes until dst is 4-byte aligned
+	const uint32_t h = head < n ? head : n;
+	{
+		Pred p = lane < U32(h);
+		gst8(dst, lane, gld8(src, lane, p), p);
+	}
+	const uint32_t words = (n - h) >> 2;
+	const uint32_t smis = (uint32_t)((uintptr_t)(src + h) & 3u);
+	const uint8_t* sbase = src + h - smis; // 4-byte aligned
+	const uint32_t sh = smis * 8u;
+	for (uint32_t o = 0; o < words; o += 64) {
+		U32 k = U32(o) + lane;
+		Pred p = k < U32(words);
+		U32 lo = gld32(sbase, k * 4u, p);
+		U32 v = lo;
+		if (sh) { // the upper word still holds at least one byte of [src, src + n)
+			U32 hi = gld32(sbase, k * 4u + 4u, p);
+			v = (lo >> U32(sh)) | (hi << U32(32u - sh));
+		}
+		gst32(dst + h, k * 4u, v, p);
+	}
+	const uint32_t done = h + words * 4;
+	{
+		Pred p = lane < U32(n - done);
+		gst8(dst + done, lane, gld8(src + done, lane, p), p);
+	}
+}
+
+// ---- encode side -----------------------------------------------------------------------------------
+
+// One full block: HBM -> LDS -> encoded image -> 16-byte aligned slot.  Returns the encoded size.
+WV_FN uint32_t encode_block_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint8_t* slot, bool allow_lz)
+{
+	load_block(lds, L.in, src, 256 * T);
+	wave_sync();
+	uint32_t size = encode_full_block(lds, L, T, allow_lz);
+	store_block(slot, lds, L.out, (size + 15u) & ~15u); // slots are padded to 16 bytes
+	return size;
+}
+
+// The tail of a superblock payload: n < 256*T bytes -> [254] + partial block (block_compress.h:1277-1293).
+WV_FN uint32_t encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t n, uint8_t* slot)
+{
+	const U32 lane = lane_id();
+	load_block(lds, L.in, src, n);
+	wave_sync();
+	// pad with the last byte up to a whole block (:967-968)
+	U32 last = lds_ld8(lds, U32(L.in + n - 1));
+	for (uint32_t o = n; o < 256 * T; o += 64)
+		lds_st8(lds, U32(L.in + o) + lane, last, (U32(o) + lane) < U32(256 * T));
+	wave_sync();
+	const uint32_t lines = n / (16 * T);
+	uint32_t size = encode_partial_lines(lds, L, T, lines);
+	// bytes after the last complete line stay raw (:1011-1018)
+	const uint32_t rem = n - lines * 16 * T;
+	for (uint32_t o = 0; o < rem; o += 64) {
+		Pred p = (U32(o) + lane) < U32(rem);
+		U32 b = lds_ld8(lds, U32(L.in + lines * 16 * T + o) + sel(p, lane, U32(0u)));
+		lds_put_bits(lds + L.out, (U32(size + o) + lane) * 8u, b, p);
+	}
+	wave_sync();
+	size += rem;
+	store_block(slot, lds, L.out, (size + 15u) & ~15u);
+	return size;
+}
+
+// ---- decode side -----------------------------------------------------------------------------------
+
+WV_HD uint32_t max_block_bytes(uint32_t T) { return 256 * T + header_bytes(T) + 1; }
+WV_HD uint32_t max_tail_bytes(uint32_t T) { return 280 * T + header_bytes(T) + 2; }
+// window size: room for the largest block plus a few KiB so that small blocks are decoded several per refill
+WV_HD uint32_t window_bytes(uint32_t T) { return align16(max_tail_bytes(T) + 2048 + 32); }
+
+WV_HD DecLayout make_dec_layout(uint32_t T)
+{
+	DecLayout L;
+	L.win = 0;
+	L.img = window_bytes(T) + 32;
+	L.total = align16(L.img + 256 * T + 32);
+	return L;
+}
+
+// Decode the payload of one BLOCK superblock (code 1): `csize` compressed bytes at src -> `dsize`
+// bytes at dst.  Returns dsize, or DEC_ERROR on a malformed / truncated stream.
+WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t dsize)
+{
+	const U32 lane = lane_id();
+	const uint32_t bs = 256 * T, hs = header_bytes(T);
+	if (dsize == 0 || csize == 0)
+		return 0;
+	const uint32_t nblocks = dsize / bs;
+	if (csize < hs + T && nblocks) // block_compress.h:1813-1815
+		return DEC_ERROR;
+	const uint32_t wcap = window_bytes(T);
+	const uint32_t mis = (uint32_t)((uintptr_t)src & 15u); // the window is filled from the 16-byte aligned address below src
+	const uint8_t* abase = src - mis;
+	uint32_t wstart = 0, wfill = 0; // window holds abase[wstart, wstart + wfill)
+	uint32_t consumed = 0;          // payload bytes consumed so far
+
+	auto ensure = [&](uint32_t need) {
+		// make payload bytes [consumed, consumed + need) resident (need already clipped to the payload)
+		uint32_t a = consumed + mis; // offset from abase
+		if (a >= wstart && a + need <= wstart + wfill)
+			return;
+		wstart = a & ~15u;
+		uint32_t endoff = csize + mis;
+		wfill = endoff - wstart < wcap ? endoff - wstart : wcap;
+		copy_g2l(lds, L.win, abase + wstart, wfill);
+		wave_sync();
+	};
+
+	for (uint32_t b = 0; b < nblocks; ++b) {
+		uint32_t left = csize - consumed;
+		uint32_t need = left < max_block_bytes(T) ? left : max_block_bytes(T);
+		ensure(need);
+		uint32_t n = decode_block(lds, L, T, consumed + mis - wstart, need, 16, true);
+		if (n == DEC_ERROR)
+			return DEC_ERROR;
+		store_block(dst + (size_t)b * bs, lds, L.img, bs);
+		wave_sync();
+		consumed += n;
+	}
+	const uint32_t tail = dsize - nblocks * bs;
+	if (tail) { // [254] + partial block (:1862-1876, 1749-1795)
+		if (consumed == csize)
+			return DEC_ERROR;
+		uint32_t left = csize - consumed;
+		uint32_t need = left < max_tail_bytes(T) ? left : max_tail_bytes(T);
+		ensure(need);
+		uint32_t cur = consumed + mis - wstart;
+		if (win_u8(lds + L.win, cur) != BLOCK_PARTIAL)
+			return DEC_ERROR;
+		const uint32_t lines = tail / (16 * T);
+		uint32_t n = 0;
+		if (lines) {
+			n = decode_block(lds, L, T, cur + 1, need - 1, lines, false);
+			if (n == DEC_ERROR)
+				return DEC_ERROR;
+		}
+		const uint32_t rem = tail - lines * 16 * T;
+		if (1 + n + rem > need)
+			return DEC_ERROR;
+		for (uint32_t o = 0; o < rem; o += 64) {
+			Pred p = (U32(o) + lane) < U32(rem);
+			U32 v = lds_ld8(lds + L.win, U32(cur + 1 + n + o) + sel(p, lane, U32(0u)));
+			lds_st8(lds, U32(L.img + lines * 16 * T + o) + lane, v, p);
+		}
+		wave_sync();
+		store_block(dst + (size_t)nblocks * bs, lds, L.img, tail);
+		consumed += 1 + n + rem;
+	}
+	return dsize;
+}
+
+} // namespace codec

@@ -1,0 +1,524 @@
+// wavevec.h -- one-wavefront (64 lanes) vocabulary used by the block codec.
+//
+// The codec (block_codec.h) is written once against this vocabulary:
+//   * compiled by hipcc for gfx950, U32 is the lane's own 32-bit register and every operation is
+//     a plain VALU instruction, a DPP/ds_bpermute cross-lane move, a ballot or an LDS access;
+//   * compiled by g++ with -DWV_HOST_EMULATION, U32 is an array of 64 lanes executed in lockstep, so
+//     the exact same codec source can be diffed against the CPU oracle without a GPU
+//     (tests/emul/ -- test infrastructure only, never part of the shipped library).
+//
+// Rules the codec follows so that both builds mean the same thing:
+//   * control flow only on wave-uniform scalars (plain uint32_t / bool obtained from ballot, readlane...);
+//   * lane-varying choices through sel() and predicated LDS operations;
+//   * LDS is a byte-addressed scratch private to the wave; accesses of one wave are ordered by wave_sync().
+#pragma once
+#include <stdint.h>
+
+#ifdef WV_HOST_EMULATION
+// ------------------------------------------------------------------------------------------------
+// host emulation: 64 lanes in lockstep
+// ------------------------------------------------------------------------------------------------
+#include <string.h>
+#define WV_FN static inline
+#define WV_HD static inline
+namespace wv {
+constexpr int WAVE = 64;
+
+struct Pred {
+	bool l[WAVE];
+};
+struct U32 {
+	uint32_t l[WAVE];
+	U32() {}
+	U32(uint32_t s)
+	{
+		for (int i = 0; i < WAVE; ++i) l[i] = s;
+	}
+};
+typedef uint8_t* Lds;
+
+#define WV_BINOP(op)                                                                                                   \
+	WV_FN U32 operator op(const U32& a, const U32& b)                                                                  \
+	{                                                                                                                  \
+		U32 r;                                                                                                         \
+		for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] op b.l[i];                                                      \
+		return r;                                                                                                      \
+	}
+WV_BINOP(+) WV_BINOP(-) WV_BINOP(*) WV_BINOP(&) WV_BINOP(|) WV_BINOP(^)
+#undef WV_BINOP
+WV_FN U32 operator<<(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] << (b.l[i] & 31);
+	return r;
+}
+WV_FN U32 operator>>(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] >> (b.l[i] & 31);
+	return r;
+}
+WV_FN U32 operator~(const U32& a)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = ~a.l[i];
+	return r;
+}
+#define WV_CMP(op)                                                                                                     \
+	WV_FN Pred operator op(const U32& a, const U32& b)                                                                 \
+	{                                                                                                                  \
+		Pred r;                                                                                                        \
+		for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] op b.l[i];                                                      \
+		return r;                                                                                                      \
+	}
+WV_CMP(==) WV_CMP(!=) WV_CMP(<) WV_CMP(<=) WV_CMP(>) WV_CMP(>=)
+#undef WV_CMP
+WV_FN Pred operator&(const Pred& a, const Pred& b)
+{
+	Pred r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] && b.l[i];
+	return r;
+}
+WV_FN Pred operator|(const Pred& a, const Pred& b)
+{
+	Pred r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] || b.l[i];
+	return r;
+}
+WV_FN Pred operator!(const Pred& a)
+{
+	Pred r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = !a.l[i];
+	return r;
+}
+WV_FN Pred pred_all(bool v)
+{
+	Pred r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = v;
+	return r;
+}
+WV_FN U32 sel(const Pred& p, const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = p.l[i] ? a.l[i] : b.l[i];
+	return r;
+}
+WV_FN U32 lane_id()
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)i;
+	return r;
+}
+WV_FN U32 umin(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] < b.l[i] ? a.l[i] : b.l[i];
+	return r;
+}
+WV_FN U32 umax(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] > b.l[i] ? a.l[i] : b.l[i];
+	return r;
+}
+WV_FN U32 popc(const U32& a)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)__builtin_popcount(a.l[i]);
+	return r;
+}
+// number of bits needed to represent a (0 for 0)
+WV_FN U32 bitlen(const U32& a)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i] ? 32u - (uint32_t)__builtin_clz(a.l[i]) : 0u;
+	return r;
+}
+// 32x32 -> high 32 bits of the 64-bit product
+WV_FN U32 mulhi(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(((uint64_t)a.l[i] * b.l[i]) >> 32);
+	return r;
+}
+WV_FN uint64_t ballot(const Pred& p)
+{
+	uint64_t m = 0;
+	for (int i = 0; i < WAVE; ++i) m |= (uint64_t)(p.l[i] ? 1 : 0) << i;
+	return m;
+}
+WV_FN uint32_t readlane(const U32& a, uint32_t lane) { return a.l[lane & 63]; }
+// lane i reads a[src[i] & 63]
+WV_FN U32 shfl(const U32& a, const U32& src)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[src.l[i] & 63];
+	return r;
+}
+// lane i reads a[i - n]; lanes < n read `fill`
+WV_FN U32 shfl_up(const U32& a, uint32_t n, uint32_t fill)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)i >= n ? a.l[i - (int)n] : fill;
+	return r;
+}
+// lane i reads a[i ^ m]
+WV_FN U32 shfl_xor(const U32& a, uint32_t m)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i ^ (int)m];
+	return r;
+}
+// rotate right by n inside each aligned group of 16 lanes: lane i reads a[(i & ~15) | ((i + n) & 15)]
+WV_FN U32 row_ror(const U32& a, uint32_t n)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[(i & ~15) | ((i - (int)n) & 15)];
+	return r;
+}
+// shift right by n inside each aligned group of 16 lanes; the first n lanes of each group read `fill`
+WV_FN U32 row_shr(const U32& a, uint32_t n, uint32_t fill)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(i & 15) >= n ? a.l[i - (int)n] : fill;
+	return r;
+}
+WV_FN void wave_sync() {}
+
+// ---- LDS (byte addressed; 32-bit accesses must be 4-byte aligned unless named *_unaligned) ----
+WV_FN U32 lds_ld8(Lds m, const U32& a)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = m[a.l[i]];
+	return r;
+}
+WV_FN U32 lds_ld32(Lds m, const U32& a)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) memcpy(&r.l[i], m + (a.l[i] & ~3u), 4);
+	return r;
+}
+WV_FN void lds_ld64(Lds m, const U32& a, U32& lo, U32& hi)
+{
+	for (int i = 0; i < WAVE; ++i) {
+		memcpy(&lo.l[i], m + (a.l[i] & ~3u), 4);
+		memcpy(&hi.l[i], m + (a.l[i] & ~3u) + 4, 4);
+	}
+}
+WV_FN void lds_st32(Lds m, const U32& a, const U32& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) memcpy(m + (a.l[i] & ~3u), &v.l[i], 4);
+}
+WV_FN void lds_st8(Lds m, const U32& a, const U32& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) m[a.l[i]] = (uint8_t)v.l[i];
+}
+WV_FN void lds_or32(Lds m, const U32& a, const U32& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			uint32_t t;
+			memcpy(&t, m + (a.l[i] & ~3u), 4);
+			t |= v.l[i];
+			memcpy(m + (a.l[i] & ~3u), &t, 4);
+		}
+}
+
+// ---- global memory (plain pointers on the host) ----
+struct U128 {
+	U32 x, y, z, w;
+};
+WV_FN U32 gld8(const uint8_t* g, const U32& off, const Pred& p)
+{
+	U32 r(0u);
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) r.l[i] = g[off.l[i]];
+	return r;
+}
+WV_FN U32 gld32(const uint8_t* g, const U32& off, const Pred& p) // off multiple of 4, g 4-byte aligned
+{
+	U32 r(0u);
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) memcpy(&r.l[i], g + off.l[i], 4);
+	return r;
+}
+WV_FN U128 gld128(const uint8_t* g, const U32& off, const Pred& p) // 16-byte aligned
+{
+	U128 r;
+	r.x = r.y = r.z = r.w = U32(0u);
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			memcpy(&r.x.l[i], g + off.l[i], 4);
+			memcpy(&r.y.l[i], g + off.l[i] + 4, 4);
+			memcpy(&r.z.l[i], g + off.l[i] + 8, 4);
+			memcpy(&r.w.l[i], g + off.l[i] + 12, 4);
+		}
+	return r;
+}
+WV_FN void gst8(uint8_t* g, const U32& off, const U32& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) g[off.l[i]] = (uint8_t)v.l[i];
+}
+WV_FN void gst32(uint8_t* g, const U32& off, const U32& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) memcpy(g + off.l[i], &v.l[i], 4);
+}
+WV_FN void gst128(uint8_t* g, const U32& off, const U128& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			memcpy(g + off.l[i], &v.x.l[i], 4);
+			memcpy(g + off.l[i] + 4, &v.y.l[i], 4);
+			memcpy(g + off.l[i] + 8, &v.z.l[i], 4);
+			memcpy(g + off.l[i] + 12, &v.w.l[i], 4);
+		}
+}
+WV_FN U128 lds_ld128(Lds m, const U32& a) // 16-byte aligned
+{
+	U128 r;
+	for (int i = 0; i < WAVE; ++i) {
+		memcpy(&r.x.l[i], m + a.l[i], 4);
+		memcpy(&r.y.l[i], m + a.l[i] + 4, 4);
+		memcpy(&r.z.l[i], m + a.l[i] + 8, 4);
+		memcpy(&r.w.l[i], m + a.l[i] + 12, 4);
+	}
+	return r;
+}
+WV_FN void lds_st128(Lds m, const U32& a, const U128& v, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			memcpy(m + a.l[i], &v.x.l[i], 4);
+			memcpy(m + a.l[i] + 4, &v.y.l[i], 4);
+			memcpy(m + a.l[i] + 8, &v.z.l[i], 4);
+			memcpy(m + a.l[i] + 12, &v.w.l[i], 4);
+		}
+}
+} // namespace wv
+
+#else
+// ------------------------------------------------------------------------------------------------
+// gfx950 device build
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define WV_FN static __device__ __forceinline__
+#define WV_HD static __host__ __device__ __forceinline__
+namespace wv {
+constexpr int WAVE = 64;
+typedef uint32_t U32;
+typedef bool Pred;
+typedef uint8_t* Lds; // points into __shared__ memory
+
+WV_FN Pred pred_all(bool v) { return v; }
+WV_FN U32 sel(Pred p, U32 a, U32 b) { return p ? a : b; }
+WV_FN U32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+WV_FN U32 umin(U32 a, U32 b) { return a < b ? a : b; }
+WV_FN U32 umax(U32 a, U32 b) { return a > b ? a : b; }
+WV_FN U32 popc(U32 a) { return (U32)__builtin_popcount(a); }
+WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
+WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
+WV_FN uint64_t ballot(Pred p) { return __ballot(p); }
+WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }
+WV_FN U32 shfl(U32 a, U32 src) { return (U32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)a); }
+WV_FN U32 shfl_up(U32 a, uint32_t n, uint32_t fill)
+{
+	U32 l = lane_id();
+	U32 v = (U32)__builtin_amdgcn_ds_bpermute((int)((l - n) << 2), (int)a);
+	return l >= n ? v : fill;
+}
+WV_FN U32 shfl_xor(U32 a, uint32_t m) { return (U32)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)a); }
+
+// DPP controls (gfx9): row_shr:n = 0x110+n, row_ror:n = 0x120+n
+template <int CTRL>
+WV_FN U32 dpp_zero(U32 a) // lanes without a source read 0
+{
+	return (U32)__builtin_amdgcn_update_dpp(0, (int)a, CTRL, 0xf, 0xf, true);
+}
+WV_FN U32 row_ror(U32 a, uint32_t n)
+{
+	switch (n) {
+		case 1: return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0x121, 0xf, 0xf, false);
+		case 2: return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0x122, 0xf, 0xf, false);
+		case 4: return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0x124, 0xf, 0xf, false);
+		default: return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0x128, 0xf, 0xf, false);
+	}
+}
+WV_FN U32 row_shr(U32 a, uint32_t n, uint32_t fill)
+{
+	U32 v;
+	switch (n) {
+		case 1: v = dpp_zero<0x111>(a); break;
+		case 2: v = dpp_zero<0x112>(a); break;
+		case 4: v = dpp_zero<0x114>(a); break;
+		default: v = dpp_zero<0x118>(a); break;
+	}
+	return (lane_id() & 15u) >= n ? v : fill;
+}
+// orders this wave's LDS accesses (program order is enough for one wave on the hardware; this
+// stops the compiler from moving accesses across the point)
+WV_FN void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+WV_FN U32 lds_ld8(Lds m, U32 a) { return m[a]; }
+WV_FN U32 lds_ld32(Lds m, U32 a) { return *(const uint32_t*)(m + (a & ~3u)); }
+WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
+{
+	lo = *(const uint32_t*)(m + (a & ~3u));
+	hi = *(const uint32_t*)(m + (a & ~3u) + 4);
+}
+WV_FN void lds_st32(Lds m, U32 a, U32 v, Pred p)
+{
+	if (p) *(uint32_t*)(m + (a & ~3u)) = v;
+}
+WV_FN void lds_st8(Lds m, U32 a, U32 v, Pred p)
+{
+	if (p) m[a] = (uint8_t)v;
+}
+WV_FN void lds_or32(Lds m, U32 a, U32 v, Pred p)
+{
+	if (p) __hip_atomic_fetch_or((uint32_t*)(m + (a & ~3u)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// ---- global memory ----
+struct U128 {
+	U32 x, y, z, w;
+};
+WV_FN U32 gld8(const uint8_t* g, U32 off, Pred p) { return p ? (U32)g[off] : 0u; }
+WV_FN U32 gld32(const uint8_t* g, U32 off, Pred p) { return p ? *(const uint32_t*)(g + off) : 0u; }
+WV_FN U128 gld128(const uint8_t* g, U32 off, Pred p)
+{
+	U128 r = { 0u, 0u, 0u, 0u };
+	if (p) {
+		uint4 v = *(const uint4*)(g + off);
+		r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+	}
+	return r;
+}
+WV_FN void gst8(uint8_t* g, U32 off, U32 v, Pred p)
+{
+	if (p) g[off] = (uint8_t)v;
+}
+WV_FN void gst32(uint8_t* g, U32 off, U32 v, Pred p)
+{
+	if (p) *(uint32_t*)(g + off) = v;
+}
+WV_FN void gst128(uint8_t* g, U32 off, const U128& v, Pred p)
+{
+	if (p) *(uint4*)(g + off) = make_uint4(v.x, v.y, v.z, v.w);
+}
+WV_FN U128 lds_ld128(Lds m, U32 a)
+{
+	uint4 v = *(const uint4*)(m + a);
+	U128 r = { v.x, v.y, v.z, v.w };
+	return r;
+}
+WV_FN void lds_st128(Lds m, U32 a, const U128& v, Pred p)
+{
+	if (p) *(uint4*)(m + a) = make_uint4(v.x, v.y, v.z, v.w);
+}
+} // namespace wv
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// helpers written in the vocabulary above (identical for both builds)
+// ------------------------------------------------------------------------------------------------
+namespace wv {
+
+WV_FN bool any(const Pred& p) { return ballot(p) != 0; }
+
+// unaligned little-endian 32-bit read from LDS (two aligned reads + funnel)
+WV_FN U32 lds_ld32_unaligned(Lds m, const U32& a)
+{
+	U32 lo, hi;
+	lds_ld64(m, a, lo, hi); // reads the aligned dword containing a and the next one
+	U32 sh = (a & 3u) << 3;
+	// (hi:lo) >> sh ; sh in {0,8,16,24}
+	return sel(sh == U32(0u), lo, (lo >> sh) | (hi << (U32(32u) - sh)));
+}
+
+// OR `nbits` (<= 32) bits of value into the LDS bit stream at bit position bitpos (LSB first);
+// the buffer must have been zeroed and have 4 bytes of slack after the last piece
+WV_FN void lds_put_bits(Lds m, const U32& bitpos, const U32& value, const Pred& p)
+{
+	U32 addr = (bitpos >> 5) << 2;
+	U32 sh = bitpos & 31u;
+	lds_or32(m, addr, value << sh, p);
+	U32 hi = sel(sh == U32(0u), U32(0u), value >> (U32(32u) - sh));
+	lds_or32(m, addr + 4u, hi, p & (hi != U32(0u)));
+}
+
+// all-reduce inside each aligned group of 4 lanes
+WV_FN U32 quad_add(U32 x)
+{
+	x = x + shfl_xor(x, 1);
+	return x + shfl_xor(x, 2);
+}
+WV_FN U32 quad_min(U32 x)
+{
+	x = umin(x, shfl_xor(x, 1));
+	return umin(x, shfl_xor(x, 2));
+}
+WV_FN U32 quad_max(U32 x)
+{
+	x = umax(x, shfl_xor(x, 1));
+	return umax(x, shfl_xor(x, 2));
+}
+// all-reduce (sum) inside each aligned group of 16 lanes
+WV_FN U32 row_add(U32 x)
+{
+	x = x + row_ror(x, 8);
+	x = x + row_ror(x, 4);
+	x = x + row_ror(x, 2);
+	return x + row_ror(x, 1);
+}
+// exclusive prefix sum inside each aligned group of 16 lanes
+WV_FN U32 row_excl_scan(const U32& x)
+{
+	U32 s = x;
+	s = s + row_shr(s, 1, 0);
+	s = s + row_shr(s, 2, 0);
+	s = s + row_shr(s, 4, 0);
+	s = s + row_shr(s, 8, 0);
+	return s - x;
+}
+// inclusive prefix sum over the 64 lanes
+WV_FN U32 wave_incl_scan(U32 s)
+{
+	s = s + shfl_up(s, 1, 0);
+	s = s + shfl_up(s, 2, 0);
+	s = s + shfl_up(s, 4, 0);
+	s = s + shfl_up(s, 8, 0);
+	s = s + shfl_up(s, 16, 0);
+	return s + shfl_up(s, 32, 0);
+}
+
+// ---- SWAR on four packed bytes ----
+WV_FN U32 bytes_sub(const U32& a, const U32& b) // per-byte a - b (mod 256)
+{
+	const U32 H(0x80808080u);
+	return ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);
+}
+WV_FN U32 bytes_add(const U32& a, const U32& b) // per-byte a + b (mod 256)
+{
+	const U32 H(0x80808080u);
+	return ((a & ~H) + (b & ~H)) ^ ((a ^ b) & H);
+}
+// 0x80 in every byte of x that is zero, 0 elsewhere
+WV_FN U32 bytes_zero_mask(const U32& x)
+{
+	const U32 L(0x7f7f7f7fu);
+	return ~(((x & L) + L) | x | L);
+}
+// compress the four 0x80 flags of a zero mask into bits 0..3
+WV_FN U32 zero_mask_to_bits(const U32& z) { return (((z >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu; }
+WV_FN U32 byte_of(const U32& x, int k) { return (x >> U32(8u * (uint32_t)k)) & 0xFFu; }
+WV_FN U32 bytes_splat(const U32& b) { return (b & 0xFFu) * 0x01010101u; }
+} // namespace wv

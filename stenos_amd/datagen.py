@@ -102,3 +102,59 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
         x = (128 + 100 * np.sin(0.01 * np.arange(n))).astype(np.int64) + (u % np.uint64(5)).astype(np.int64) - 2
         return (x & 0xFF).astype(np.uint8)
     raise ValueError(f"unknown kind {kind}")
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side generation (torch), same sequences as the numpy generators above
+# ------------------------------------------------------------------------------------------------
+def _lsr(z, k: int):
+    """logical shift right of an int64 torch tensor"""
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def splitmix64_torch(seed: int, n: int, device, start: int = 0):
+    import torch
+
+    def wrap(v: int) -> int:  # two's complement int64 view of a uint64 constant
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    idx = torch.arange(start + 1, start + n + 1, dtype=torch.int64, device=device)
+    z = idx * wrap(0x9E3779B97F4A7C15) + wrap(seed)
+    z = (z ^ _lsr(z, 30)) * wrap(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * wrap(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25):
+    """Flat uint8 CUDA tensor holding n elements of T bytes; kinds: sorted_i32, rand, rand12, walk, sine."""
+    import torch
+
+    out = torch.empty(n * T, dtype=torch.uint8, device=device)
+    carry = 0
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        if kind == "sorted_i32":
+            v = torch.arange(s, s + m, dtype=torch.int64, device=device).to(torch.int32)
+        elif kind == "rand":
+            assert (T * chunk) % 8 == 0
+            nb = (m * T + 7) // 8
+            v = splitmix64_torch(seed, nb, device, start=s * T // 8).view(torch.uint8)[: m * T]
+        elif kind == "rand12":
+            v = (splitmix64_torch(seed, m, device, start=s) & 0xFFF).to(torch.int32)
+        elif kind == "walk":
+            u = splitmix64_torch(seed, m, device, start=s)
+            # u mod 17 for the unsigned 64-bit value: (hi * 2^32 + lo) mod 17 with 2^32 mod 17 = 1
+            lo, hi = u & 0xFFFFFFFF, _lsr(u, 32)
+            steps = (hi + lo) % 17 - 8
+            x = torch.cumsum(steps, 0) + carry
+            carry = int(x[-1].item())
+            v = {2: torch.int16, 4: torch.int32, 8: torch.int64}[T]
+            v = x.to(v)
+        elif kind == "sine":
+            x = torch.sin(torch.arange(s, s + m, dtype=torch.float64, device=device) * 0.001)
+            v = x if T == 8 else x.to(torch.float32)
+        else:
+            raise ValueError(kind)
+        out[s * T:(s + m) * T] = v.contiguous().view(torch.uint8).reshape(-1)
+    return out

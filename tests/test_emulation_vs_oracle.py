@@ -1,0 +1,75 @@
+"""The wave-level codec SOURCE of the product (stenos_amd/csrc/*.h) compiled for the host as a
+64-lane lockstep emulation (tests/emul) and diffed against the oracle.  Runs without a GPU; it proves
+the kernel logic, not the shipped binary (the -m gpu tests do that through the C ABI)."""
+import ctypes
+import os
+import subprocess
+from ctypes import c_int, c_size_t, c_void_p
+
+import numpy as np
+import pytest
+
+from _libs import ROOT, has_error, np_ptr
+from stenos_amd.datagen import generate
+
+KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst"]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    d = os.path.join(ROOT, "tests", "emul")
+    subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(d, "libstenos_emul.so"))
+    lib.emul_block_compress.restype = c_size_t
+    lib.emul_block_compress.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_int]
+    lib.emul_block_decompress.restype = c_size_t
+    lib.emul_block_decompress.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int]
+    lib.emul_copy_g2g.restype = None
+    lib.emul_copy_g2g.argtypes = [c_void_p, c_void_p, c_size_t]
+    return lib
+
+
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 7, 8, 12, 16, 24, 33, 64])
+def test_kernel_logic_matches_oracle(oracle, emul, T):
+    sizes = [16, 100, 255, 256, 257, 300, 512, 1280, 4099] if T <= 16 else [16, 257, 1280]
+    for kind in KINDS + (["rand12"] if T == 4 else []):
+        for n in sizes:
+            data = generate(kind, T, n, 42 + n)
+            nb = data.nbytes
+            ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+            out = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r2 = emul.emul_block_compress(np_ptr(data), T, nb, np_ptr(out), 1)
+            assert r1 == r2, (kind, n)
+            assert np.array_equal(ref[:r1], out[:r1]), (kind, n)
+            for mis in (0, 7):
+                dec = np.zeros(nb + 64, dtype=np.uint8)
+                r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), mis)
+                assert r3 == nb, (kind, n, mis)
+                assert np.array_equal(dec[:nb], data), (kind, n, mis)
+                assert not dec[nb:].any()
+
+
+def test_truncated_streams_are_rejected_not_overrun(oracle, emul):
+    """Every prefix of a valid payload must decode to an error (block_compress.h:1560, 1575, 1591-1598, 1642)."""
+    for kind, T in (("burst", 4), ("dict16", 4), ("walk", 2), ("runs", 8)):
+        data = generate(kind, T, 700, 3)
+        nb = data.nbytes
+        ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+        r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+        for cut in list(range(0, min(r1, 80))) + list(range(max(0, r1 - 40), r1)):
+            dec = np.zeros(nb + 64, dtype=np.uint8)
+            r3 = emul.emul_block_decompress(np_ptr(ref), cut, T, nb, np_ptr(dec), 0)
+            assert has_error(r3) or (cut == 0 and r3 == 0), (kind, cut, r3)
+
+
+def test_copy_any_alignment(emul):
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, size=5000, dtype=np.uint8)
+    for so in range(0, 8):
+        for do in range(0, 5):
+            for n in (0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1026, 3000):
+                dst = np.zeros(4096, dtype=np.uint8)
+                emul.emul_copy_g2g(np_ptr(dst) + do, np_ptr(src) + so, n)
+                assert np.array_equal(dst[do:do + n], src[so:so + n]), (so, do, n)
+                assert not dst[:do].any() and not dst[do + n:].any(), (so, do, n)

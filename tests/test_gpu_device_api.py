@@ -1,0 +1,104 @@
+"""Device-resident path (include/stenos_hip.h) at sizes the oracle cannot reach in seconds: size
+independent properties -- encode -> decode round trips on torch CUDA tensors, indexed and walked
+decoding agree, frames equal the host-ABI frames, compressed size is additive over superblocks."""
+import numpy as np
+import pytest
+
+from stenos_amd.api import Stenos, StenosError
+from stenos_amd.datagen import generate, generate_torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def st():
+    import torch
+
+    assert torch.cuda.is_available()
+    s = Stenos(level=1)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("kind,T,n", [("rand12", 4, (256 << 20) // 4), ("walk", 2, (128 << 20) // 2 + 77), ("sine", 8, (128 << 20) // 8 + 5),
+                                      ("rand", 4, (64 << 20) // 4 + 1), ("sorted_i32", 4, 50_000_000)])
+def test_device_roundtrip_large(st, kind, T, n):
+    import torch
+
+    src = generate_torch(kind, T, n, 42)
+    dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device="cuda")
+    csize = st.compress(src, T, dst)
+    assert 8 < csize <= st.bound(src.numel())
+    idx, nsb = st.last_index()
+    sb = 131072 // (256 * T) * 256 * T
+    assert nsb == (src.numel() + sb - 1) // sb
+    # indexed decode
+    back = torch.zeros_like(src)
+    assert st.decompress(dst, T, csize, back, index_ptr=idx) == src.numel()
+    assert torch.equal(back, src)
+    # frame-only decode (device walks the superblock chain); the index buffer is reused, so copy the frame first
+    frame = dst[:csize].clone()
+    back.zero_()
+    assert st.decompress(frame, T, csize, back, index_ptr=None) == src.numel()
+    assert torch.equal(back, src)
+    # idempotence: same input, same frame
+    dst2 = torch.empty_like(dst)
+    assert st.compress(src, T, dst2) == csize
+    assert torch.equal(dst2[:csize], dst[:csize])
+
+
+def test_device_frame_equals_host_abi_frame(st):
+    import torch
+
+    data = generate("burst", 4, 3_000_001, 5)
+    src = torch.from_numpy(data).cuda()
+    dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device="cuda")
+    csize = st.compress(src, 4, dst)
+    out = np.zeros(st.bound(data.nbytes), dtype=np.uint8)
+    r = st.lib.stenos_compress(data.ctypes.data, 4, data.nbytes, out.ctypes.data, out.nbytes, 1)
+    assert r == csize
+    assert np.array_equal(dst[:csize].cpu().numpy(), out[:r])
+
+
+def test_superblock_additivity(st):
+    """Superblocks are independent units (stenos.cpp:893-904): compressing two halves cut at a superblock
+    boundary gives the same superblock bytes as compressing the whole."""
+    import torch
+
+    T, sb = 4, 131072
+    src = generate_torch("rand12", T, 64 * sb // T + 333, 3)
+    dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device="cuda")
+    c_all = st.compress(src, T, dst)
+    whole = dst[:c_all].cpu().numpy()
+    cut = 40 * sb
+    a = torch.empty(st.bound(cut), dtype=torch.uint8, device="cuda")
+    ca = st.compress(src[:cut].contiguous(), T, a)
+    b = torch.empty(st.bound(src.numel() - cut), dtype=torch.uint8, device="cuda")
+    cb = st.compress(src[cut:].contiguous(), T, b)
+    assert c_all == ca + cb - 8
+    assert np.array_equal(whole[8:ca], a[8:ca].cpu().numpy())
+    assert np.array_equal(whole[ca:], b[8:cb].cpu().numpy())
+
+
+def test_dst_too_small_on_device(st):
+    import torch
+
+    src = generate_torch("rand", 4, 100_000, 1)
+    small = torch.full((1000,), 7, dtype=torch.uint8, device="cuda")
+    with pytest.raises(StenosError):
+        st.compress(src, 4, small)
+    assert bool((small == 7).all())
+
+
+def test_async_compress_then_finish(st):
+    import torch
+
+    src = generate_torch("walk", 2, 5_000_000, 2)
+    dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device="cuda")
+    assert st.compress(src, 2, dst, wait=False) == 0
+    csize = st.finish()
+    back = torch.zeros_like(src)
+    idx, _ = st.last_index()
+    assert st.decompress(dst, 2, csize, back, index_ptr=idx, wait=False) == 0
+    assert st.finish() == src.numel()
+    assert torch.equal(back, src)

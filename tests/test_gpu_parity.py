@@ -1,0 +1,223 @@
+"""Parity tests proper: the shipped libstenos.so (HIP kernels on the MI355X) through its C ABI against
+the oracle, the golden vectors generated from the compiled reference, and -- when the prebuilt
+oracle/_ref travelled to the box -- the reference library itself.  Bar: bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from _libs import has_error, load_ref, np_ptr, oracle_compress
+from stenos_amd.api import load_library
+from stenos_amd.datagen import generate
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "manifest.json")) as f:
+    MANIFEST = json.load(f)["cases"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = load_library()
+    assert lib.stenos_hip_device_count() >= 1, "no HIP device: the GPU tests cannot run"
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ctx(lib):
+    c = lib.stenos_make_context()
+    yield c
+    lib.stenos_destroy_context(c)
+
+
+def gpu_compress(lib, ctx, data, T, level=1, dst_size=None):
+    lib.stenos_set_level(ctx, level)
+    cap = lib.stenos_bound(data.nbytes) if dst_size is None else dst_size
+    out = np.full(cap + 64, 0xA5, dtype=np.uint8)
+    r = lib.stenos_compress_generic(ctx, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
+    assert (out[cap:] == 0xA5).all(), "wrote past dst_size"
+    return r, (out[:r].copy() if not has_error(r) else None)
+
+
+def gpu_decompress(lib, ctx, frame, T, nbytes):
+    out = np.full(nbytes + 64, 0x5A, dtype=np.uint8)
+    r = lib.stenos_decompress_generic(ctx, np_ptr(frame), T, frame.nbytes, np_ptr(out), nbytes)
+    assert (out[nbytes:] == 0x5A).all(), "wrote past the decompressed size"
+    return r, out[:nbytes]
+
+
+def _golden_cases():
+    # every golden case of supported shape (level-1 path: bytesoftype > 1)
+    return [e for e in MANIFEST if e["T"] > 1]
+
+
+@pytest.mark.parametrize("entry", _golden_cases(), ids=lambda e: f"{e['kind']}-T{e['T']}-n{e['n']}")
+def test_golden_vectors(lib, ctx, entry):
+    """Frames are byte-identical to those of the compiled reference (tests/golden/manifest.json)."""
+    data = generate(entry["kind"], entry["T"], entry["n"], entry["seed"])
+    for level in (0, 1):
+        r, frame = gpu_compress(lib, ctx, data, entry["T"], level)
+        assert not has_error(r), hex(r)
+        assert r == entry[f"l{level}_size"]
+        assert hashlib.sha256(frame.tobytes()).hexdigest() == entry[f"l{level}_sha256"]
+    r2, back = gpu_decompress(lib, ctx, frame, entry["T"], data.nbytes)
+    assert r2 == data.nbytes
+    assert np.array_equal(back, data)
+
+
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 24, 33, 64])
+def test_matrix_against_oracle(lib, ctx, oracle, T):
+    """The reference's own test matrix (tests_comp_decomp.cpp:182-211): bytesoftype x distribution x odd
+    sizes, plus sizes around the superblock boundary; GPU frames equal the oracle's, and the GPU decodes
+    the oracle's frames."""
+    per_sb = 131072 // (256 * T) * 256
+    sizes = [0, 1, 15, 16, 17, 100, 255, 256, 257, 511, 1280, 4099, per_sb - 1, per_sb, per_sb + 1, 2 * per_sb + 300]
+    for kind in ("rand", "same", "sorted", "walk", "dict16", "runs", "burst", "ramp"):
+        for n in sizes:
+            data = generate(kind, T, n, 77 + n)
+            r1, ref = oracle_compress(oracle, data, T, 1)
+            r2, frame = gpu_compress(lib, ctx, data, T, 1)
+            assert r1 == r2, (kind, n, hex(r2))
+            assert np.array_equal(ref, frame), (kind, n)
+            r3, back = gpu_decompress(lib, ctx, ref, T, data.nbytes)
+            assert r3 == data.nbytes and np.array_equal(back, data), (kind, n)
+
+
+def test_readme_example(lib, ctx):
+    data = generate("sorted_i32", 4, 1_000_000, 0)
+    r, frame = gpu_compress(lib, ctx, data, 4, 1)
+    assert r == 70464
+    assert hashlib.sha256(frame.tobytes()).hexdigest() == "1af6d3035454fff7c0b8a23490dba172c14328795010b563283304c831ed0681"
+    # one-shot entry points (reference stenos.cpp:1210-1226)
+    out = np.zeros(lib.stenos_bound(data.nbytes), dtype=np.uint8)
+    assert lib.stenos_compress(np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes, 1) == 70464
+    back = np.zeros(data.nbytes, dtype=np.uint8)
+    assert lib.stenos_decompress(np_ptr(out), 4, 70464, np_ptr(back), back.nbytes) == data.nbytes
+    assert np.array_equal(back, data)
+
+
+@pytest.mark.parametrize("T,kind,n", [(4, "rand12", 5_000_011), (2, "walk", 9_000_001), (8, "sine", 2_000_003), (4, "dict16", 3_000_017),
+                                      (4, "rand", 1_000_003), (4, "burst", 4_000_001)])
+def test_medium_sizes_against_oracle(lib, ctx, oracle, T, kind, n):
+    data = generate(kind, T, n, 42)
+    r1, ref = oracle_compress(oracle, data, T, 1)
+    r2, frame = gpu_compress(lib, ctx, data, T, 1)
+    assert r1 == r2
+    assert np.array_equal(ref, frame)
+    r3, back = gpu_decompress(lib, ctx, frame, T, data.nbytes)
+    assert r3 == data.nbytes and np.array_equal(back, data)
+
+
+@pytest.mark.parametrize("T,kind,n", [(4, "rand", 300), (4, "walk", 5000), (2, "burst", 70001), (8, "dict16", 3000), (4, "rand12", 32768 + 200)])
+def test_shrinking_dst(lib, ctx, oracle, T, kind, n):
+    """Compress must succeed when dst_size >= bound, may only fail with an error below it, and never
+    writes past dst_size (tests_comp_decomp.cpp:103-121, 163-177).  When it succeeds the frame is the
+    oracle's full-capacity frame."""
+    data = generate(kind, T, n, 5)
+    bound = lib.stenos_bound(data.nbytes)
+    _, ref = oracle_compress(oracle, data, T, 1)
+    dst_size = bound
+    step = max(10, data.nbytes // 10)
+    while True:
+        r, frame = gpu_compress(lib, ctx, data, T, 1, dst_size)
+        if has_error(r):
+            assert dst_size < bound
+        else:
+            assert r <= dst_size and np.array_equal(frame, ref), dst_size
+        if dst_size == 0:
+            break
+        dst_size = max(0, dst_size - step)
+
+
+def test_exact_superblock_multiples_decode(lib, ctx, oracle):
+    """The reference decoder rejects these frames (stenos.cpp:1115-1116, 1131); this library decodes them."""
+    for T, nsb in ((4, 1), (4, 3), (2, 2), (8, 5)):
+        data = generate("walk", T, nsb * (131072 // T), 9)
+        r, frame = gpu_compress(lib, ctx, data, T, 1)
+        r1, ref = oracle_compress(oracle, data, T, 1)
+        assert r == r1 and np.array_equal(frame, ref)
+        r2, back = gpu_decompress(lib, ctx, frame, T, data.nbytes)
+        assert r2 == data.nbytes and np.array_equal(back, data)
+
+
+def test_corrupt_frames_give_errors(lib, ctx):
+    data = generate("burst", 4, 100_000, 3)
+    r, frame = gpu_compress(lib, ctx, data, 4, 1)
+    out = np.zeros(data.nbytes, dtype=np.uint8)
+    # truncated frame
+    for cut in (r - 1, r // 2, 20, 12, 9):
+        assert has_error(lib.stenos_decompress_generic(ctx, np_ptr(frame), 4, cut, np_ptr(out), out.nbytes))
+    # unknown superblock code
+    bad = frame.copy()
+    bad[8] = 9
+    assert has_error(lib.stenos_decompress_generic(ctx, np_ptr(bad), 4, r, np_ptr(out), out.nbytes))
+    # garbage block stream: must return (an error or garbage), never hang or write out of bounds
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        bad = frame.copy()
+        pos = rng.integers(12, r, size=64)
+        bad[pos] = rng.integers(0, 256, size=64, dtype=np.uint8)
+        guard = np.full(data.nbytes + 64, 0x5A, dtype=np.uint8)
+        lib.stenos_decompress_generic(ctx, np_ptr(bad), 4, r, np_ptr(guard), data.nbytes)
+        assert (guard[data.nbytes:] == 0x5A).all()
+
+
+def test_custom_block_size_and_private_api(lib, oracle):
+    """stenos_set_block_size frames (byte 255 + 4-byte size, stenos.cpp:868-874) and the single-superblock
+    private API used by stenos::cvector (stenos.cpp:768-804)."""
+    c = lib.stenos_make_context()
+    assert lib.stenos_set_block_size(c, 2) == 0  # superblock = 256*T*4
+    data = generate("walk", 4, 20_000, 1)
+    out = np.zeros(lib.stenos_bound(data.nbytes), dtype=np.uint8)
+    r = lib.stenos_compress_generic(c, np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes)
+    assert not has_error(r) and out[0] == 255 and int.from_bytes(out[8:12].tobytes(), "little") == 4096
+    back = np.zeros(data.nbytes, dtype=np.uint8)
+    assert lib.stenos_decompress_generic(c, np_ptr(out), 4, r, np_ptr(back), back.nbytes) == data.nbytes
+    assert np.array_equal(back, data)
+    # one superblock through the private API: [code][csize:3][payload] equals the oracle's payload
+    blk = data[:4096]
+    sb = np.zeros(4096 + 64, dtype=np.uint8)
+    r = lib.stenos_private_compress_block(c, np_ptr(blk), 4, 4096, 4096, np_ptr(sb), sb.nbytes)
+    ref = np.zeros(8192, dtype=np.uint8)
+    rp = oracle.so_block_compress(np_ptr(blk), 4, 4096, np_ptr(ref), ref.nbytes)
+    assert r == rp + 4 and sb[0] == 1 and np.array_equal(sb[4:r], ref[:rp])
+    assert lib.stenos_private_block_size(np_ptr(sb), r) == r
+    back = np.zeros(4096, dtype=np.uint8)
+    assert lib.stenos_private_decompress_block(c, np_ptr(sb), 4, 4096, r, np_ptr(back), 4096) == 4096
+    assert np.array_equal(back, blk)
+    lib.stenos_destroy_context(c)
+
+
+def test_unsupported_requests_fail_loudly(lib):
+    c = lib.stenos_make_context()
+    data = generate("walk", 4, 5000, 1)
+    out = np.zeros(lib.stenos_bound(data.nbytes), dtype=np.uint8)
+    lib.stenos_set_level(c, 3)  # levels >= 2: next round (needs lz4-dry + zstd orchestration)
+    assert has_error(lib.stenos_compress_generic(c, np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes))
+    lib.stenos_set_level(c, 1)
+    assert has_error(lib.stenos_compress_generic(c, np_ptr(data), 1, data.nbytes, np_ptr(out), out.nbytes))  # bytesoftype 1
+    lib.stenos_set_max_nanoseconds(c, 1000)
+    assert has_error(lib.stenos_compress_generic(c, np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes))
+    lib.stenos_destroy_context(c)
+
+
+def test_reference_library_decodes_gpu_frames(lib, ctx):
+    """When the prebuilt reference travelled to the box: it decodes what the GPU encoded, the GPU
+    decodes what it encoded, and both encoders agree byte for byte."""
+    ref = load_ref(det=True)
+    if ref is None:
+        pytest.skip("oracle/_ref/*.so not present")
+    for T, kind, n in ((4, "rand12", 300_001), (2, "walk", 500_003), (8, "sine", 100_001), (4, "dict16", 200_003)):
+        data = generate(kind, T, n, 42)
+        r, frame = gpu_compress(lib, ctx, data, T, 1)
+        out = np.zeros(ref.stenos_bound(data.nbytes), dtype=np.uint8)
+        rr = ref.stenos_compress(np_ptr(data), T, data.nbytes, np_ptr(out), out.nbytes, 1)
+        assert rr == r and np.array_equal(out[:rr], frame)
+        back = np.zeros(data.nbytes, dtype=np.uint8)
+        assert ref.stenos_decompress(np_ptr(frame), T, r, np_ptr(back), back.nbytes) == data.nbytes
+        assert np.array_equal(back, data)
+        r2, back2 = gpu_decompress(lib, ctx, out[:rr], T, data.nbytes)
+        assert r2 == data.nbytes and np.array_equal(back2, data)
