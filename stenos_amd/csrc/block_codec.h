@@ -217,19 +217,50 @@ WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint3
 	wave_sync();
 }
 
+// What the frame assembly needs to know about an encoded block to reproduce the reference's
+// capacity rules (block_compress.h:1214, 1225, 1241; block_compress_partial :984, 994, 1013):
+//   info = full | need << 15 | eligible << 30 | lz_ok << 31
+//   full : sum of the plane sizes (the non-LZ encoding is header_bytes + full)
+//   need : bytes of capacity, counted from the block's first byte, that the non-LZ encoding requires
+//          (the largest of the reference's "dst + x > dst_end" tests)
+//   eligible: the mini-LZ may be tried (T % 4 == 0 and 3 * full > 256 * T); lz_ok: it succeeded
+struct BlockInfo {
+	uint32_t size; // bytes of the emitted encoding
+	uint32_t info;
+};
+WV_HD uint32_t info_full(uint32_t info) { return info & 0x7FFFu; }
+WV_HD uint32_t info_need(uint32_t info) { return (info >> 15) & 0x7FFFu; }
+WV_HD bool info_eligible(uint32_t info) { return (info >> 30) & 1u; }
+WV_HD bool info_lz_ok(uint32_t info) { return (info >> 31) & 1u; }
+
 // Turn plane sizes into plane offsets (relative to the block start, after the type nibbles).
-// Returns the sum of the plane sizes ("full_size", block_compress.h:1189-1207).
-WV_FN uint32_t plane_offsets(Lds lds, const Layout& L, uint32_t T)
+// Returns the sum of the plane sizes ("full_size", block_compress.h:1189-1207); *need receives the
+// capacity requirement of the plane loop: max(hs + full, max over non-RAW planes of offset + size + slack)
+// with slack 16 for full blocks (:1241) and, for partial blocks, the reference's
+// 8 + (8 + sum of row costs) test (:989-995) or offset + 1 for SAME planes (:984).
+WV_FN uint32_t plane_offsets(Lds lds, const Layout& L, uint32_t T, bool full_block, uint32_t lines, uint32_t* need)
 {
 	const U32 lane = lane_id();
 	const Pred valid = lane < U32(T);
 	U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
+	U32 type = pi & 0xFFu;
 	U32 size = pi >> 8;
 	U32 incl = wave_incl_scan(size);
 	U32 off = U32(header_bytes(T)) + incl - size;
-	lds_st32(lds, U32(L.plinfo) + lane * 4u, (pi & 0xFFu) | (off << 8), valid);
+	lds_st32(lds, U32(L.plinfo) + lane * 4u, type | (off << 8), valid);
 	wave_sync();
-	return readlane(incl, 63);
+	const uint32_t full = readlane(incl, 63);
+	U32 req;
+	if (full_block)
+		req = sel(valid & (type != U32(PLANE_RAW)), off + size + 16u, U32(0u));
+	else {
+		const uint32_t nh = (lines + 1) >> 1;
+		req = sel(valid, sel(type == U32(PLANE_SAME), off + 1u, off + (size - nh + 8u) + 8u), U32(0u));
+	}
+	uint32_t m = wave_max(req);
+	const uint32_t whole = header_bytes(T) + full;
+	*need = m > whole ? m : whole;
+	return full;
 }
 
 // Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
@@ -501,40 +532,52 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	return produced;
 }
 
-// Encode the full block at L.in into the output image (zeroed here).  Returns its size in bytes.
+// Encode the full block at L.in into the output image (zeroed here).
 // allow_lz mirrors the reference's capacity condition for the LZ attempt (block_compress.h:1214).
-WV_FN uint32_t encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
+WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
 {
 	lds_zero(lds, L.out, out_capacity(T));
 	for (uint32_t g = 0; g < T; g += 4)
 		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16);
-	uint32_t full = plane_offsets(lds, L, T);
-	if (allow_lz && T % 4 == 0 && full * 3 > 256 * T) { // (:1210)
+	uint32_t need;
+	uint32_t full = plane_offsets(lds, L, T, true, 16, &need);
+	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
+	BlockInfo r;
+	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
+	if (allow_lz && eligible) {
 		uint32_t n = lz_try(lds, L, T, full, 0);
-		if (n)
-			return n + 1;
+		if (n) {
+			r.size = n + 1;
+			r.info |= 1u << 31;
+			return r;
+		}
 		// nothing was written to the image on failure
 	}
 	emit_planes(lds, L, T, 0, 16);
-	return header_bytes(T) + full;
+	r.size = header_bytes(T) + full;
+	return r;
 }
 
 // Encode the `lines` complete rows of a partial block (block_compress_partial, block_compress.h:947-1009).
 // L.in must hold the tail padded to 256*T bytes with its last byte.  The image receives
 // [254][plane types][planes] starting at byte 0; returns the bytes written (the caller appends the
-// remaining raw bytes).
-WV_FN uint32_t encode_partial_lines(Lds lds, const Layout& L, uint32_t T, uint32_t lines)
+// remaining raw bytes) and, in *need, the capacity the reference's tests require counted from the 254 byte.
+WV_FN uint32_t encode_partial_lines(Lds lds, const Layout& L, uint32_t T, uint32_t lines, uint32_t* need)
 {
 	lds_zero(lds, L.out, out_capacity(T));
 	lds_put_bits(lds + L.out, U32(0u), U32(BLOCK_PARTIAL), lane_id() == U32(0u));
+	*need = 2; // dst + 2 > dst_end (:1284)
 	if (lines == 0) {
 		wave_sync();
 		return 1;
 	}
 	for (uint32_t g = 0; g < T; g += 4)
 		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines);
-	uint32_t full = plane_offsets(lds, L, T);
+	uint32_t pneed;
+	uint32_t full = plane_offsets(lds, L, T, false, lines, &pneed);
 	emit_planes(lds, L, T, 1, lines);
+	if (1 + pneed > *need)
+		*need = 1 + pneed;
 	return 1 + header_bytes(T) + full;
 }
 

@@ -122,9 +122,9 @@ struct stenos_context_s {
 	// device state
 	bool probed = false, usable = false;
 	DevBuf in, out;                                  // staging for the host-pointer ABI
-	DevBuf slots, bsize, boff, sbcsize, sbcode, sboff; // workspace of the encode pipeline / decode index
-	DevBuf misc;                                     // [0,8) total, [8,12) status, [64,320) override payload
-	uint64_t* h_total = nullptr;                     // pinned: total (8 B) + status (4 B)
+	DevBuf slots, bsize, binfo, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
+	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [64,320) override payload
+	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
 	hipStream_t job_stream = nullptr;
 	int job_kind = 0; // 0 none, 1 compress, 2 decompress
@@ -145,7 +145,7 @@ struct stenos_context_s {
 	}
 	~stenos_context_s()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &boff, &sbcsize, &sbcode, &sboff, &misc };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc };
 		for (DevBuf* b : all)
 			b->release();
 		if (h_total)
@@ -212,88 +212,100 @@ size_t check_supported(const stenos_context_s* ctx, size_t T, int level)
 size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, size_t bytes, uint8_t* d_dst, size_t dst_size, int level,
 			const FramePlan& f, bool frame_header, hipStream_t stream)
 {
-	const size_t header = frame_header ? f.header : 0;
 	const uint64_t nblocks = f.nfull + (f.tail ? 1 : 0);
 	const uint32_t stride = stenos_k_slot_stride((uint32_t)T);
-	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) || !ctx->sbcsize.ensure((f.nsb + 1) * 4) ||
-	    !ctx->sbcode.ensure(f.nsb + 1) || !ctx->sboff.ensure((f.nsb + 2) * 8) || !ctx->misc.ensure(4096))
+	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
+	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
+	    !ctx->sboff.ensure((f.nsb + 2) * 8) || !ctx->misc.ensure(4096))
 		return STENOS_ERROR_ALLOC;
 	if (level >= 1 && !ctx->slots.ensure((nblocks + 1) * (size_t)stride))
 		return STENOS_ERROR_ALLOC;
 
-	uint32_t override_code = 0, override_size = 0;
 	const size_t last_bytes = bytes - (f.nsb - 1) * f.sb;
-	if (level >= 1 && last_bytes < 128) { // small input: direct zstd, zstd level 1 (stenos.cpp:435-437, zstd_wrapper.h:49-56)
-		if (!zstd().ok)
-			return STENOS_ERROR_ZSTD_INTERNAL;
-		uint8_t raw[128], comp[512];
-		if (hipMemcpyAsync(raw, d_src + (bytes - last_bytes), last_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	const bool tiny_last = level >= 1 && last_bytes < 128; // small input: direct zstd (stenos.cpp:435-437)
+	if (tiny_last && !zstd().ok)
+		return STENOS_ERROR_ZSTD_INTERNAL;
+
+	uint8_t* misc = ctx->misc.as<uint8_t>();
+	codec::FrameJob j;
+	j.src = d_src;
+	j.dst = d_dst;
+	j.dst_size = dst_size;
+	j.slots = ctx->slots.as<uint8_t>();
+	j.bsize = ctx->bsize.as<uint32_t>();
+	j.binfo = ctx->binfo.as<uint32_t>();
+	j.boff = ctx->boff.as<uint32_t>();
+	j.sb_csize = ctx->sbcsize.as<uint32_t>();
+	j.sb_code = ctx->sbcode.as<uint8_t>();
+	j.sb_need = ctx->sbneed.as<uint32_t>();
+	j.sb_off = ctx->sboff.as<uint64_t>();
+	j.total = (uint64_t*)misc;
+	j.status = (uint32_t*)(misc + 12);
+	j.first_flagged = (uint32_t*)(misc + 16);
+	j.override_payload = misc + 64;
+	j.nfull = f.nfull;
+	j.nsb = f.nsb;
+	j.total_bytes = bytes;
+	j.tail_bytes = f.tail;
+	j.bps = f.bps;
+	j.sb_bytes = (uint32_t)f.sb;
+	j.slot_stride = stride;
+	j.T = (uint32_t)T;
+	j.shift_byte = frame_header ? f.shift : 0xFFFFFFFFu;
+	j.header_bytes = frame_header ? (uint32_t)f.header : 0u;
+	j.force_copy = level == 0 ? 1u : 0u;
+	j.tiny_last = tiny_last ? 1u : 0u;
+	j.override_code = 0;
+
+	const uint32_t init[2] = { 0u, 0xFFFFFFFFu }; // status, first_flagged
+	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	if (level >= 1 && stenos_k_launch_encode(j, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	if (stenos_k_launch_plan(j, stream) != hipSuccess || stenos_k_launch_scan(j, stream) != hipSuccess ||
+	    stenos_k_launch_resolve(j, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+
+	if (tiny_last) {
+		// The reference hands zstd the rest of the caller's buffer as capacity (stenos.cpp:666, 895), and
+		// zstd's result depends on it, so the final offset of this last superblock must be known first.
+		uint64_t off_last = 0;
+		uint32_t status = 0;
+		uint8_t raw[128], comp[256];
+		if (hipMemcpyAsync(&off_last, j.sb_off + (f.nsb - 1), 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		    hipMemcpyAsync(&status, j.status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		    hipMemcpyAsync(raw, d_src + (bytes - last_bytes), last_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 		    hipStreamSynchronize(stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
-		size_t r = zstd().compress(comp, sizeof(comp), raw, last_bytes, 1);
+		if (status || dst_size < off_last + 4) // an earlier superblock did not fit / no room for this header (stenos.cpp:427-429)
+			return STENOS_ERROR_DST_OVERFLOW;
+		const size_t room = dst_size - (size_t)off_last - 4;
+		size_t cap = room > sizeof(comp) ? sizeof(comp) : room; // above ZSTD_compressBound(127) the capacity no longer matters
+		size_t r = zstd().compress(comp, cap, raw, last_bytes, 1); // zstd level 1 (zstd_wrapper.h:49-56)
 		const uint8_t* payload = comp;
-		if (zstd().is_error(r) || r > last_bytes) { // -> MEMCPY (stenos.cpp:668-669)
-			override_code = 6;
-			override_size = (uint32_t)last_bytes;
+		uint32_t code = 2, csize = (uint32_t)r;
+		if (zstd().is_error(r) || r > last_bytes) { // -> MEMCPY (stenos.cpp:668-669, 366-367)
+			if (room < last_bytes)
+				return STENOS_ERROR_DST_OVERFLOW;
+			code = 6;
+			csize = (uint32_t)last_bytes;
 			payload = raw;
 		}
-		else {
-			override_code = 2;
-			override_size = (uint32_t)r;
-		}
-		if (hipMemcpyAsync(ctx->misc.as<uint8_t>() + 64, payload, override_size, hipMemcpyHostToDevice, stream) != hipSuccess ||
-		    hipStreamSynchronize(stream) != hipSuccess) // payload lives on this stack frame
+		const uint64_t end = off_last + 4 + csize;
+		const uint8_t code8 = (uint8_t)code;
+		if (hipMemcpyAsync(misc + 64, payload, csize, hipMemcpyHostToDevice, stream) != hipSuccess ||
+		    hipMemcpyAsync(j.sb_code + (f.nsb - 1), &code8, 1, hipMemcpyHostToDevice, stream) != hipSuccess ||
+		    hipMemcpyAsync(j.sb_csize + (f.nsb - 1), &csize, 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+		    hipMemcpyAsync(j.sb_off + f.nsb, &end, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+		    hipMemcpyAsync(j.total, &end, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+		    hipStreamSynchronize(stream) != hipSuccess) // the sources live on this stack frame
 			return STENOS_ERROR_UNDEFINED;
+		j.override_code = code;
 	}
-
-	if (level >= 1) {
-		if (stenos_k_launch_encode(d_src, f.nfull, f.tail, (uint32_t)T, ctx->slots.as<uint8_t>(), ctx->bsize.as<uint32_t>(), stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-	}
-	SuperblockPlanArgs pa;
-	pa.bsize = ctx->bsize.as<uint32_t>();
-	pa.boff = ctx->boff.as<uint32_t>();
-	pa.sb_csize = ctx->sbcsize.as<uint32_t>();
-	pa.sb_code = ctx->sbcode.as<uint8_t>();
-	pa.nfull = f.nfull;
-	pa.nsb = f.nsb;
-	pa.total_bytes = bytes;
-	pa.tail_bytes = f.tail;
-	pa.bps = f.bps;
-	pa.sb_bytes = (uint32_t)f.sb;
-	pa.override_code = override_code;
-	pa.override_size = override_size;
-	pa.force_copy = level == 0 ? 1u : 0u;
-	if (stenos_k_launch_plan(pa, stream) != hipSuccess)
+	if (stenos_k_launch_pack(j, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	uint64_t* d_total = ctx->misc.as<uint64_t>();
-	if (stenos_k_launch_scan(ctx->sbcsize.as<uint32_t>(), f.nsb, header, ctx->sboff.as<uint64_t>(), d_total, stream) != hipSuccess)
-		return STENOS_ERROR_UNDEFINED;
-	PackArgs ka;
-	ka.src = d_src;
-	ka.dst = d_dst;
-	ka.dst_size = dst_size;
-	ka.slots = ctx->slots.as<uint8_t>();
-	ka.bsize = ctx->bsize.as<uint32_t>();
-	ka.boff = ctx->boff.as<uint32_t>();
-	ka.sb_csize = ctx->sbcsize.as<uint32_t>();
-	ka.sb_code = ctx->sbcode.as<uint8_t>();
-	ka.sb_off = ctx->sboff.as<uint64_t>();
-	ka.total = d_total;
-	ka.override_payload = ctx->misc.as<uint8_t>() + 64;
-	ka.nfull = f.nfull;
-	ka.nsb = f.nsb;
-	ka.total_bytes = bytes;
-	ka.tail_bytes = f.tail;
-	ka.bps = f.bps;
-	ka.sb_bytes = (uint32_t)f.sb;
-	ka.slot_stride = stride;
-	ka.T = (uint32_t)T;
-	ka.shift_byte = frame_header ? f.shift : 0xFFFFFFFFu;
-	ka.override_code = override_code;
-	if (stenos_k_launch_pack(ka, stream) != hipSuccess)
-		return STENOS_ERROR_UNDEFINED;
-	if (hipMemcpyAsync(ctx->h_total, d_total, 8, hipMemcpyDeviceToHost, stream) != hipSuccess)
+	// total (8 bytes) and the encode status (4 bytes at +12) travel together
+	if (hipMemcpyAsync(ctx->h_total, misc, 16, hipMemcpyDeviceToHost, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	ctx->last_nsb = f.nsb;
 	return 0;
@@ -323,6 +335,7 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 			return STENOS_ERROR_UNDEFINED;
 		ctx->last_nsb = 0;
 		ctx->h_total[0] = f.header;
+		ctx->h_total[1] = 0;
 		ctx->job_kind = 1;
 		ctx->job_stream = stream;
 		ctx->job_dst_size = dst_size;
@@ -450,7 +463,7 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 	a.status = d_status;
 	if (stenos_k_launch_decode(a, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	if (hipMemcpyAsync((uint8_t*)ctx->h_total + 8, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
+	if (hipMemcpyAsync((uint8_t*)ctx->h_total + 32, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	ctx->job_kind = 2;
 	ctx->job_stream = stream;
@@ -568,11 +581,11 @@ size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t byte
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	size_t r = compress_device(ctx, ctx->in.p, bytesoftype, bytes, ctx->out.p, bound, nullptr, true);
+	// the device buffer holds `bound` bytes, which every frame fits; the caller's dst_size is the logical
+	// capacity (a frame that does not fit is reported, nothing is written past dst_size)
+	size_t r = compress_device(ctx, ctx->in.p, bytesoftype, bytes, ctx->out.p, dst_size, nullptr, true);
 	if (is_err(r))
 		return r;
-	if (r > dst_size) // the caller's buffer is too small: report, never write past it
-		return STENOS_ERROR_DST_OVERFLOW;
 	if (hipMemcpy(dst, ctx->out.p, r, hipMemcpyDeviceToHost) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	return r;
@@ -735,12 +748,12 @@ size_t stenos_private_compress_block(stenos_context* ctx, const void* src, size_
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	e = enqueue_compress(ctx, ctx->in.as<uint8_t>(), bytesoftype, bytes, ctx->out.as<uint8_t>(), bytes + 4, ctx->level, f, false, nullptr);
+	e = enqueue_compress(ctx, ctx->in.as<uint8_t>(), bytesoftype, bytes, ctx->out.as<uint8_t>(), dst_size, ctx->level, f, false, nullptr);
 	if (is_err(e))
 		return e;
 	ctx->job_kind = 1;
 	ctx->job_stream = nullptr;
-	ctx->job_dst_size = bytes + 4;
+	ctx->job_dst_size = dst_size;
 	size_t r = finish_job(ctx);
 	if (is_err(r))
 		return r;
@@ -886,9 +899,10 @@ size_t finish_job(stenos_context_s* ctx)
 	ctx->job_kind = 0;
 	if (kind == 1) {
 		const uint64_t total = ctx->h_total[0];
-		return total > ctx->job_dst_size ? STENOS_ERROR_DST_OVERFLOW : (size_t)total;
+		const uint32_t estatus = *(const uint32_t*)((const uint8_t*)ctx->h_total + 12);
+		return (estatus || total > ctx->job_dst_size) ? STENOS_ERROR_DST_OVERFLOW : (size_t)total;
 	}
-	const uint32_t status = *(const uint32_t*)((const uint8_t*)ctx->h_total + 8);
+	const uint32_t status = *(const uint32_t*)((const uint8_t*)ctx->h_total + 32);
 	if (status & DECODE_STATUS_TRUNCATED)
 		return STENOS_ERROR_SRC_OVERFLOW;
 	if (status & DECODE_STATUS_INVALID)

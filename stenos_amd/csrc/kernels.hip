@@ -4,8 +4,10 @@
 //   encode_blocks      one wavefront per 256-element block: HBM -> LDS -> encoded image -> 16-byte
 //                      aligned slot in the workspace, size to bsize[]            (block_compress.h:1152-1298)
 //   plan_superblocks   one wavefront per superblock: payload size, BLOCK vs COPY decision
-//                      (stenos.cpp:606-615), offsets of its blocks
+//                      (stenos.cpp:606-615), offsets of its blocks, capacity requirement
 //   scan_superblocks   exclusive scan of the superblock sizes -> byte offset of every superblock header
+//   resolve_frame      one wavefront: exact replay of the reference's capacity rules for the superblocks
+//                      the plan flagged (normally none or the last; pipeline.h)
 //   pack_frame         one wavefront per block: [code][csize:3] headers, block payloads or raw copy,
 //                      frame header (stenos.cpp:862-874)
 // Decode pipeline:
@@ -14,7 +16,6 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
-#include "superblock_codec.h"
 
 using namespace codec;
 using namespace wv;
@@ -23,56 +24,25 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 
-__global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t nfull, uint32_t tail_bytes,
-						    uint32_t T, uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ bsize)
+__global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t nfull, uint32_t tail_bytes, uint32_t T,
+						    uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ bsize,
+						    uint32_t* __restrict__ binfo)
 {
 	const Layout L = make_layout(T, true);
 	const uint64_t b = blockIdx.x;
-	uint32_t size;
+	BlockInfo r;
 	if (b < nfull)
-		size = encode_block_job(g_lds, L, T, src + b * (uint64_t)(256 * T), slots + b * (uint64_t)slot_stride, true);
+		r = encode_block_job(g_lds, L, T, src + b * (uint64_t)(256 * T), slots + b * (uint64_t)slot_stride, true);
 	else
-		size = encode_tail_job(g_lds, L, T, src + nfull * (uint64_t)(256 * T), tail_bytes, slots + nfull * (uint64_t)slot_stride);
-	if (threadIdx.x == 0)
-		bsize[b] = size;
+		r = encode_tail_job(g_lds, L, T, src + nfull * (uint64_t)(256 * T), tail_bytes, slots + nfull * (uint64_t)slot_stride);
+	if (threadIdx.x == 0) {
+		bsize[b] = r.size;
+		binfo[b] = r.info;
+	}
 }
 
-// One wavefront per superblock.  bps = full blocks per full superblock.
-__global__ __launch_bounds__(64) void plan_superblocks(SuperblockPlanArgs a)
-{
-	const uint64_t s = blockIdx.x;
-	const uint32_t lane = threadIdx.x;
-	const uint64_t first = s * a.bps;
-	const uint64_t sb_begin = s * (uint64_t)a.sb_bytes;
-	const uint32_t sbytes = (uint32_t)((a.total_bytes - sb_begin) < a.sb_bytes ? (a.total_bytes - sb_begin) : a.sb_bytes);
-	// blocks of this superblock: full ones, plus the tail block when this is the last superblock
-	uint64_t last = first + a.bps < a.nfull ? first + a.bps : a.nfull;
-	uint32_t count = (uint32_t)(last - first);
-	if (s == a.nsb - 1 && a.tail_bytes)
-		count += 1;
-	uint32_t run = 0;
-	for (uint32_t o = 0; o < count; o += 64) {
-		uint32_t i = o + lane;
-		uint32_t sz = (i < count && !a.force_copy) ? a.bsize[first + i] : 0u;
-		uint32_t incl = wave_incl_scan(sz);
-		if (i < count)
-			a.boff[first + i] = run + incl - sz;
-		run += readlane(incl, 63);
-	}
-	if (lane == 0) {
-		uint32_t code = 1, csize = run;
-		if (run > sbytes || a.force_copy) { // result > bytes -> memcpy (stenos.cpp:609-610); equal is kept
-			code = 6;
-			csize = sbytes;
-		}
-		if (s == a.nsb - 1 && a.override_code) { // superblock shorter than 128 bytes: prepared by the host
-			code = a.override_code;
-			csize = a.override_size;
-		}
-		a.sb_code[s] = (uint8_t)code;
-		a.sb_csize[s] = csize;
-	}
-}
+// One wavefront per superblock.
+__global__ __launch_bounds__(64) void plan_superblocks(FrameJob j) { plan_superblock(j, blockIdx.x); }
 
 // Exclusive scan of (csize + 4) over the superblocks by one workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restrict__ csize, uint64_t nsb, uint64_t header_bytes,
@@ -81,7 +51,7 @@ __global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restr
 	__shared__ uint64_t partial[1024];
 	const uint32_t tid = threadIdx.x;
 	const uint64_t per = (nsb + 1023) / 1024;
-	const uint64_t lo = tid * per, hi = lo + per < nsb ? lo + per : nsb;
+	const uint64_t lo = tid * per < nsb ? tid * per : nsb, hi = lo + per < nsb ? lo + per : nsb;
 	uint64_t sum = 0;
 	for (uint64_t i = lo; i < hi; ++i)
 		sum += (uint64_t)csize[i] + 4;
@@ -104,40 +74,14 @@ __global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restr
 	}
 }
 
-__global__ __launch_bounds__(64) void pack_frame(PackArgs a)
+// One wavefront replays the capacity rules where the parallel plan could not clear them.
+__global__ __launch_bounds__(64) void resolve_frame(FrameJob j)
 {
-	const uint64_t b = blockIdx.x;
-	const U32 lane = lane_id();
-	const uint64_t total = *a.total;
-	if (total > a.dst_size) // never write past the caller's buffer; the host reports DST_OVERFLOW
-		return;
-	const bool is_tail = b >= a.nfull;
-	const uint64_t s = is_tail ? a.nsb - 1 : b / a.bps;
-	const uint64_t first = s * a.bps;
-	uint8_t* base = a.dst + a.sb_off[s];
-	const uint32_t code = a.sb_code[s];
-	const uint32_t csize = a.sb_csize[s];
-	if (b == 0 && a.shift_byte != 0xFFFFFFFFu) { // frame header: [shift][bytes:7 LE] (+ [superblock size:4 LE] for custom sizes)
-		uint64_t v = (uint64_t)a.shift_byte | (a.total_bytes << 8);
-		gst8(a.dst, lane, U32((uint32_t)(v >> 0)) >> (lane << 3), lane < U32(4u));
-		gst8(a.dst, lane, U32((uint32_t)(v >> 32)) >> ((lane - 4u) << 3), (lane >= U32(4u)) & (lane < U32(8u)));
-		if (a.shift_byte == 255)
-			gst8(a.dst + 8, lane, U32(a.sb_bytes) >> (lane << 3), lane < U32(4u));
-	}
-	if (b == first || (is_tail && a.nfull == first)) { // superblock header [code][csize:3 LE]
-		uint32_t h = code | (csize << 8);
-		gst8(base, lane, U32(h) >> (lane << 3), lane < U32(4u));
-	}
-	if (code == 1)
-		copy_g2g(base + 4 + a.boff[b], a.slots + b * (uint64_t)a.slot_stride, a.bsize[b]);
-	else if (code == 6 && !(s == a.nsb - 1 && a.override_code)) {
-		const uint32_t bs = 256 * a.T;
-		uint32_t n = is_tail ? a.tail_bytes : bs;
-		copy_g2g(base + 4 + (uint32_t)(b - first) * (uint64_t)bs, a.src + b * (uint64_t)bs, n);
-	}
-	else if (is_tail) // payload prepared by the host (superblock < 128 bytes)
-		copy_g2g(base + 4, a.override_payload, csize);
+	const Layout L = make_layout(j.T, true);
+	resolve_capacity(g_lds, L, j);
 }
+
+__global__ __launch_bounds__(64) void pack_frame(FrameJob j) { pack_block(j, blockIdx.x); }
 
 // Serial walk of the superblock chain by one lane: off[s] = byte offset of superblock s's header.
 __global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* __restrict__ off,
@@ -215,36 +159,46 @@ size_t stenos_k_encode_lds_bytes(uint32_t T) { return make_layout(T, true).total
 size_t stenos_k_decode_lds_bytes(uint32_t T) { return make_dec_layout(T).total; }
 uint32_t stenos_k_slot_stride(uint32_t T) { return out_capacity(T); }
 
-hipError_t stenos_k_launch_encode(const uint8_t* src, uint64_t nfull, uint32_t tail_bytes, uint32_t T, uint8_t* slots, uint32_t* bsize,
-				  hipStream_t stream)
+hipError_t stenos_k_launch_encode(const FrameJob& j, hipStream_t stream)
 {
-	const uint64_t nblocks = nfull + (tail_bytes ? 1 : 0);
+	const uint64_t nblocks = j.nfull + (j.tail_bytes ? 1 : 0);
 	if (nblocks == 0)
 		return hipSuccess;
-	const size_t lds = stenos_k_encode_lds_bytes(T);
+	const size_t lds = stenos_k_encode_lds_bytes(j.T);
 	hipError_t e = hipFuncSetAttribute((const void*)encode_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
-	hipLaunchKernelGGL(encode_blocks, dim3((uint32_t)nblocks), dim3(64), lds, stream, src, nfull, tail_bytes, T, slots, out_capacity(T), bsize);
+	hipLaunchKernelGGL(encode_blocks, dim3((uint32_t)nblocks), dim3(64), lds, stream, j.src, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride, j.bsize,
+			   j.binfo);
 	return hipGetLastError();
 }
 
-hipError_t stenos_k_launch_plan(const SuperblockPlanArgs& a, hipStream_t stream)
+hipError_t stenos_k_launch_plan(const FrameJob& j, hipStream_t stream)
 {
-	hipLaunchKernelGGL(plan_superblocks, dim3((uint32_t)a.nsb), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(plan_superblocks, dim3((uint32_t)j.nsb), dim3(64), 0, stream, j);
 	return hipGetLastError();
 }
 
-hipError_t stenos_k_launch_scan(const uint32_t* csize, uint64_t nsb, uint64_t header_bytes, uint64_t* off, uint64_t* total, hipStream_t stream)
+hipError_t stenos_k_launch_scan(const FrameJob& j, hipStream_t stream)
 {
-	hipLaunchKernelGGL(scan_superblocks, dim3(1), dim3(1024), 0, stream, csize, nsb, header_bytes, off, total);
+	hipLaunchKernelGGL(scan_superblocks, dim3(1), dim3(1024), 0, stream, j.sb_csize, j.nsb, (uint64_t)j.header_bytes, j.sb_off, j.total);
 	return hipGetLastError();
 }
 
-hipError_t stenos_k_launch_pack(const PackArgs& a, hipStream_t stream)
+hipError_t stenos_k_launch_resolve(const FrameJob& j, hipStream_t stream)
 {
-	const uint64_t nblocks = a.nfull + (a.tail_bytes ? 1 : 0);
-	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)nblocks), dim3(64), 0, stream, a);
+	const size_t lds = stenos_k_encode_lds_bytes(j.T);
+	hipError_t e = hipFuncSetAttribute((const void*)resolve_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(resolve_frame, dim3(1), dim3(64), lds, stream, j);
+	return hipGetLastError();
+}
+
+hipError_t stenos_k_launch_pack(const FrameJob& j, hipStream_t stream)
+{
+	const uint64_t nblocks = j.nfull + (j.tail_bytes ? 1 : 0);
+	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)nblocks), dim3(64), 0, stream, j);
 	return hipGetLastError();
 }
 

@@ -98,18 +98,19 @@ WV_FN void copy_g2g(uint8_t* dst, const uint8_t* src, uint32_t n)
 
 // ---- encode side -----------------------------------------------------------------------------------
 
-// One full block: HBM -> LDS -> encoded image -> 16-byte aligned slot.  Returns the encoded size.
-WV_FN uint32_t encode_block_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint8_t* slot, bool allow_lz)
+// One full block: HBM -> LDS -> encoded image -> 16-byte aligned slot.
+WV_FN BlockInfo encode_block_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint8_t* slot, bool allow_lz)
 {
 	load_block(lds, L.in, src, 256 * T);
 	wave_sync();
-	uint32_t size = encode_full_block(lds, L, T, allow_lz);
-	store_block(slot, lds, L.out, (size + 15u) & ~15u); // slots are padded to 16 bytes
-	return size;
+	BlockInfo r = encode_full_block(lds, L, T, allow_lz);
+	store_block(slot, lds, L.out, (r.size + 15u) & ~15u); // slots are padded to 16 bytes
+	return r;
 }
 
 // The tail of a superblock payload: n < 256*T bytes -> [254] + partial block (block_compress.h:1277-1293).
-WV_FN uint32_t encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t n, uint8_t* slot)
+// info.full is unused for tails; info.need is the capacity requirement counted from the 254 byte.
+WV_FN BlockInfo encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t n, uint8_t* slot)
 {
 	const U32 lane = lane_id();
 	load_block(lds, L.in, src, n);
@@ -120,7 +121,8 @@ WV_FN uint32_t encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8
 		lds_st8(lds, U32(L.in + o) + lane, last, (U32(o) + lane) < U32(256 * T));
 	wave_sync();
 	const uint32_t lines = n / (16 * T);
-	uint32_t size = encode_partial_lines(lds, L, T, lines);
+	uint32_t need;
+	uint32_t size = encode_partial_lines(lds, L, T, lines, &need);
 	// bytes after the last complete line stay raw (:1011-1018)
 	const uint32_t rem = n - lines * 16 * T;
 	for (uint32_t o = 0; o < rem; o += 64) {
@@ -130,8 +132,13 @@ WV_FN uint32_t encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8
 	}
 	wave_sync();
 	size += rem;
+	if (size > need) // dst + remaining > dst_end (:1013)
+		need = size;
 	store_block(slot, lds, L.out, (size + 15u) & ~15u);
-	return size;
+	BlockInfo r;
+	r.size = size;
+	r.info = need << 15;
+	return r;
 }
 
 // ---- decode side -----------------------------------------------------------------------------------

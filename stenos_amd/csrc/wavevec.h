@@ -277,6 +277,17 @@ WV_FN void gst128(uint8_t* g, const U32& off, const U128& v, const Pred& p)
 			memcpy(g + off.l[i] + 12, &v.w.l[i], 4);
 		}
 }
+// wave-uniform scalar accesses to global memory
+WV_FN uint32_t gload_uniform(const uint32_t* p) { return *p; }
+WV_FN uint32_t gload_uniform8(const uint8_t* p) { return *p; }
+WV_FN uint64_t gload_uniform64(const uint64_t* p) { return *p; }
+WV_FN void gstore_uniform(uint32_t* p, uint32_t v) { *p = v; }
+WV_FN void gstore_uniform8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
+WV_FN void gstore_uniform64(uint64_t* p, uint64_t v) { *p = v; }
+WV_FN void gmin32(uint32_t* p, uint32_t v)
+{
+	if (v < *p) *p = v;
+}
 WV_FN U128 lds_ld128(Lds m, const U32& a) // 16-byte aligned
 {
 	U128 r;
@@ -414,6 +425,26 @@ WV_FN void gst128(uint8_t* g, U32 off, const U128& v, Pred p)
 {
 	if (p) *(uint4*)(g + off) = make_uint4(v.x, v.y, v.z, v.w);
 }
+// wave-uniform scalar accesses to global memory (stores by one lane)
+WV_FN uint32_t gload_uniform(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+WV_FN uint32_t gload_uniform8(const uint8_t* p) { return *(const volatile uint8_t*)p; }
+WV_FN uint64_t gload_uniform64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
+WV_FN void gstore_uniform(uint32_t* p, uint32_t v)
+{
+	if (lane_id() == 0) *p = v;
+}
+WV_FN void gstore_uniform8(uint8_t* p, uint32_t v)
+{
+	if (lane_id() == 0) *p = (uint8_t)v;
+}
+WV_FN void gstore_uniform64(uint64_t* p, uint64_t v)
+{
+	if (lane_id() == 0) *p = v;
+}
+WV_FN void gmin32(uint32_t* p, uint32_t v)
+{
+	if (lane_id() == 0) atomicMin(p, v);
+}
 WV_FN U128 lds_ld128(Lds m, U32 a)
 {
 	uint4 v = *(const uint4*)(m + a);
@@ -488,6 +519,17 @@ WV_FN U32 row_excl_scan(const U32& x)
 	s = s + row_shr(s, 4, 0);
 	s = s + row_shr(s, 8, 0);
 	return s - x;
+}
+// maximum over the 64 lanes (uniform result)
+WV_FN uint32_t wave_max(U32 x)
+{
+	x = umax(x, shfl_xor(x, 1));
+	x = umax(x, shfl_xor(x, 2));
+	x = umax(x, shfl_xor(x, 4));
+	x = umax(x, shfl_xor(x, 8));
+	x = umax(x, shfl_xor(x, 16));
+	x = umax(x, shfl_xor(x, 32));
+	return readlane(x, 0);
 }
 // inclusive prefix sum over the 64 lanes
 WV_FN U32 wave_incl_scan(U32 s)

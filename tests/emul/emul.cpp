@@ -3,10 +3,15 @@
 // plain buffer.  Lets the CPU test-suite diff the exact kernel logic against the oracle without a GPU.
 // The shipped library never contains or calls this.
 #define WV_HOST_EMULATION 1
-#include "../../stenos_amd/csrc/superblock_codec.h"
+#include "../../stenos_amd/csrc/pipeline.h"
 
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <vector>
+typedef size_t (*zc_fn)(void*, size_t, const void*, size_t, int);
+typedef unsigned (*ze_fn)(size_t);
 
 using namespace codec;
 
@@ -36,14 +41,14 @@ size_t emul_block_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* 
 		return (size_t)-3;
 	for (size_t b = 0; b < nb; ++b) {
 		memcpy(stage, src + b * bs, bs);
-		uint32_t n = encode_block_job(lds, L, (uint32_t)T, stage, slot, allow_lz != 0);
+		uint32_t n = encode_block_job(lds, L, (uint32_t)T, stage, slot, allow_lz != 0).size;
 		memcpy(dst + off, slot, n);
 		off += n;
 	}
 	size_t rem = bytes - nb * bs;
 	if (rem) {
 		memcpy(stage, src + nb * bs, rem);
-		uint32_t n = encode_tail_job(lds, L, (uint32_t)T, stage, (uint32_t)rem, slot);
+		uint32_t n = encode_tail_job(lds, L, (uint32_t)T, stage, (uint32_t)rem, slot).size;
 		memcpy(dst + off, slot, n);
 		off += n;
 	}
@@ -71,6 +76,140 @@ size_t emul_block_decompress(const uint8_t* src, size_t csize, size_t T, size_t 
 	free(out);
 	free(lds);
 	return r == DEC_ERROR ? (size_t)-4 : r;
+}
+
+// The whole encode pipeline as capi.cpp enqueues it (encode_blocks, plan_superblocks, scan_superblocks,
+// resolve_frame, host zstd for a tiny last superblock, pack_frame), one "workgroup" after the other.
+
+size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, int level)
+{
+	const size_t ERR_DST = (size_t)-6, ERR_PARAM = (size_t)-9;
+	if (T < 2 || T > MAX_T || level < 0 || level > 1)
+		return ERR_PARAM;
+	const size_t bs = 256 * T;
+	size_t sb = bs > 131072 ? bs : (131072 / bs) * bs;
+	if (dst_size < 8)
+		return ERR_DST;
+	if (bytes == 0) {
+		memset(dst, 0, 8);
+		return 8;
+	}
+	// aligned copy of the source (the device path reads 16-byte chunks of an aligned allocation)
+	uint8_t* src = nullptr;
+	if (posix_memalign((void**)&src, 64, bytes + 64))
+		return (size_t)-3;
+	memcpy(src, src_in, bytes);
+	FrameJob j;
+	memset(&j, 0, sizeof(j));
+	j.nsb = bytes / sb + (bytes % sb ? 1 : 0);
+	j.nfull = bytes / bs;
+	j.tail_bytes = (uint32_t)(bytes % bs);
+	j.bps = (uint32_t)(sb / bs);
+	j.sb_bytes = (uint32_t)sb;
+	j.total_bytes = bytes;
+	j.T = (uint32_t)T;
+	j.shift_byte = 0;
+	j.header_bytes = 8;
+	j.force_copy = level == 0;
+	const uint64_t nblocks = j.nfull + (j.tail_bytes ? 1 : 0);
+	const size_t last_bytes = bytes - (j.nsb - 1) * sb;
+	j.tiny_last = (level >= 1 && last_bytes < 128) ? 1 : 0;
+	j.slot_stride = out_capacity((uint32_t)T);
+	uint8_t* slots = nullptr;
+	if (posix_memalign((void**)&slots, 64, (nblocks + 1) * (size_t)j.slot_stride + 64))
+		return (size_t)-3;
+	std::vector<uint32_t> bsize(nblocks + 1), binfo(nblocks + 1), boff(nblocks + 1), sbcsize(j.nsb + 1), sbneed(j.nsb + 1);
+	std::vector<uint8_t> sbcode(j.nsb + 1), frame(dst_size + 64, 0xA5), payload(256);
+	std::vector<uint64_t> sboff(j.nsb + 2);
+	uint64_t total = 0;
+	uint32_t status = 0, first_flagged = 0xFFFFFFFFu;
+	j.src = src;
+	j.dst = frame.data();
+	j.dst_size = dst_size;
+	j.slots = slots;
+	j.bsize = bsize.data();
+	j.binfo = binfo.data();
+	j.boff = boff.data();
+	j.sb_csize = sbcsize.data();
+	j.sb_code = sbcode.data();
+	j.sb_need = sbneed.data();
+	j.sb_off = sboff.data();
+	j.total = &total;
+	j.status = &status;
+	j.first_flagged = &first_flagged;
+	j.override_payload = payload.data();
+	Layout L = make_layout((uint32_t)T, true);
+	uint8_t* lds = alloc_lds(L.total);
+	if (level >= 1)
+		for (uint64_t b = 0; b < nblocks; ++b) { // encode_blocks
+			BlockInfo r = b < j.nfull ? encode_block_job(lds, L, j.T, src + b * bs, slots + b * (size_t)j.slot_stride, true)
+						 : encode_tail_job(lds, L, j.T, src + j.nfull * bs, j.tail_bytes, slots + j.nfull * (size_t)j.slot_stride);
+			bsize[b] = r.size;
+			binfo[b] = r.info;
+		}
+	for (uint64_t s = 0; s < j.nsb; ++s) // plan_superblocks
+		plan_superblock(j, s);
+	{ // scan_superblocks
+		uint64_t off = j.header_bytes;
+		for (uint64_t s = 0; s < j.nsb; ++s) {
+			sboff[s] = off;
+			off += 4 + (uint64_t)sbcsize[s];
+		}
+		sboff[j.nsb] = total = off;
+	}
+	resolve_capacity(lds, L, j); // resolve_frame
+	size_t result = 0;
+	if (j.tiny_last) { // host part of enqueue_compress
+		uint64_t off_last = sboff[j.nsb - 1];
+		if (status || dst_size < off_last + 4)
+			result = ERR_DST;
+		else {
+			static zc_fn zc = nullptr;
+			static ze_fn ze = nullptr;
+			if (!zc) {
+				void* h = dlopen("/opt/conda/lib/libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+				if (!h)
+					h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+				zc = (zc_fn)dlsym(h, "ZSTD_compress");
+				ze = (ze_fn)dlsym(h, "ZSTD_isError");
+			}
+			uint8_t comp[256];
+			size_t room = dst_size - off_last - 4;
+			size_t cap = room > sizeof(comp) ? sizeof(comp) : room;
+			size_t r = zc(comp, cap, src + (bytes - last_bytes), last_bytes, 1);
+			uint32_t code = 2, csize = (uint32_t)r;
+			const uint8_t* pl = comp;
+			if (ze(r) || r > last_bytes) {
+				if (room < last_bytes)
+					result = ERR_DST;
+				code = 6;
+				csize = (uint32_t)last_bytes;
+				pl = src + (bytes - last_bytes);
+			}
+			memcpy(payload.data(), pl, csize);
+			sbcode[j.nsb - 1] = (uint8_t)code;
+			sbcsize[j.nsb - 1] = csize;
+			sboff[j.nsb] = total = off_last + 4 + csize;
+			j.override_code = code;
+		}
+	}
+	if (!result) {
+		for (uint64_t b = 0; b < nblocks; ++b) // pack_frame
+			pack_block(j, b);
+		if (status || total > dst_size)
+			result = ERR_DST;
+		else {
+			result = (size_t)total;
+			memcpy(dst, frame.data(), total);
+		}
+		for (size_t i = (status || total > dst_size) ? 0 : total; i < frame.size(); ++i)
+			if (i >= dst_size && frame[i] != 0xA5)
+				result = (size_t)-1; // wrote past dst_size
+	}
+	free(lds);
+	free(slots);
+	free(src);
+	return result;
 }
 
 void emul_copy_g2g(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g(dst, src, (uint32_t)n); }

@@ -73,3 +73,39 @@ def test_copy_any_alignment(emul):
                 emul.emul_copy_g2g(np_ptr(dst) + do, np_ptr(src) + so, n)
                 assert np.array_equal(dst[do:do + n], src[so:so + n]), (so, do, n)
                 assert not dst[:do].any() and not dst[do + n:].any(), (so, do, n)
+
+
+@pytest.mark.parametrize("T", [2, 4, 8, 3, 12])
+def test_frame_pipeline_and_capacity_rules(oracle, emul, T):
+    """The whole encode pipeline (encode_blocks, plan, scan, resolve, pack as capi.cpp enqueues them)
+    against the oracle's serial path for dst_size = bound, larger, and smaller: same frame or both an
+    error.  Covers the reference's capacity-dependent LZ attempt (block_compress.h:1214) and
+    dst_end tests (:1225, 1241, 1284) that decide BLOCK vs COPY near the end of the buffer."""
+    from stenos_amd.datagen import splitmix64
+
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    from _libs import oracle_compress
+
+    per = 131072 // (256 * T) * 256
+    replayed = 0
+    for kind in KINDS:
+        for n in [1, 15, 17, 100, 255, 256, 257, 511, 1280, 4099, per - 1, per, per + 1, 2 * per + 300]:
+            data = generate(kind, T, n, 77 + n)
+            bound = oracle.so_bound(data.nbytes)
+            caps = [bound + 5000, bound] + [max(0, bound - int(x)) for x in (splitmix64(n, 4) % np.uint64(max(10, data.nbytes // 3)))]
+            big = None
+            for cap in caps:
+                for level in (1, 0):
+                    r1, f1 = oracle_compress(oracle, data, T, level, cap)
+                    out = np.zeros(cap + 64, dtype=np.uint8)
+                    r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, level)
+                    assert has_error(r1) == has_error(r2), (kind, n, cap, level, hex(r1), hex(r2))
+                    if not has_error(r1):
+                        assert r1 == r2 and np.array_equal(f1, out[:r2]), (kind, n, cap, level)
+                        if level == 1 and cap == bound + 5000:
+                            big = r1
+                        if level == 1 and cap == bound and big is not None and r1 != big:
+                            replayed += 1
+    if T % 4 == 0:
+        assert replayed > 0, "no case exercised the capacity replay"
