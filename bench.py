@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Stenos block codec.
+
+Metric (BASELINE.json): encode+decode GB/s of input bytes at level 1 on int32, with the compression
+ratio.  One "step" = one level-1 encode pass + one decode pass over the synthetic typed array that is
+already resident in HBM (device-pointer entry points of libstenos.so; nothing crosses PCIe except the
+8-byte frame size).  value = input bytes of all ranks / (encode + decode time).
+
+Workload at N=1: BASELINE.json configs[1], 8 GiB int32 (2^31 elements, bytesoftype 4, level 1 block
+codec only), variant (b) of SURVEY.md section 8d: uniform 12-bit values `u & 0xFFF` from splitmix64 seed 42
+-- the variant in which the codec does real work (ratio ~2.52).  The literal full-entropy variant (a),
+where every superblock falls back to COPY, is measured too and reported under "full_entropy".
+With --gpus N every rank owns its own 8 GiB superblock range of an 8*N GiB array (weak scaling, no
+data-path collective).
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--gib", type=float, default=8.0, help="input GiB per GPU (default: the 8 GiB of configs[1])")
+    p.add_argument("--kind", default="rand12", help="datagen kind for the headline workload")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-mib", type=int, default=1024)
+    return p.parse_args()
+
+
+def cpu_baseline(sample, T, sample_desc):
+    """The reference's own CPU path (oracle/_ref, unmodified sources, AVX2/BMI2 build) timed on this
+    host's cores on a bounded prefix of the same workload; falls back to the scalar C oracle ("port")."""
+    import numpy as np
+
+    from _libs import load_oracle, load_ref, np_ptr
+
+    cores = os.cpu_count() or 1
+    ref = load_ref(det=False)
+    nb = sample.nbytes
+    if ref is not None:
+        out = np.zeros(ref.stenos_bound(nb), dtype=np.uint8)
+        back = np.zeros(nb, dtype=np.uint8)
+        res = {}
+        for threads in (1, cores):
+            ctx = ref.stenos_make_context()
+            ref.stenos_set_level(ctx, 1)
+            ref.stenos_set_threads(ctx, threads)
+            best_e = best_d = 1e30
+            r = 0
+            for _ in range(3):  # best of N, as benchs/bench_to_csv.cpp:113-126
+                t = time.perf_counter()
+                r = ref.stenos_compress_generic(ctx, np_ptr(sample), T, nb, np_ptr(out), out.nbytes)
+                best_e = min(best_e, time.perf_counter() - t)
+                t = time.perf_counter()
+                d = ref.stenos_decompress_generic(ctx, np_ptr(out), T, r, np_ptr(back), nb)
+                best_d = min(best_d, time.perf_counter() - t)
+                assert d == nb
+            ref.stenos_destroy_context(ctx)
+            res[threads] = (nb / (best_e + best_d) / 1e9, nb / best_e / 1e9, nb / best_d / 1e9, nb / r)
+        use = max(res, key=lambda k: res[k][0])
+        return {"value": round(res[use][0], 3), "unit": "GB/s", "cores": use, "kind": "reference", "sample": sample_desc,
+                "encode_gbps": round(res[use][1], 3), "decode_gbps": round(res[use][2], 3), "ratio": round(res[use][3], 4),
+                "single_thread_value": round(res[1][0], 3), "host_cores": cores}
+    lib = load_oracle()
+    small = sample[: 64 << 20]
+    nb = small.nbytes
+    out = np.zeros(lib.so_bound(nb), dtype=np.uint8)
+    back = np.zeros(nb, dtype=np.uint8)
+    t = time.perf_counter()
+    r = lib.so_compress(np_ptr(small), T, nb, np_ptr(out), out.nbytes, 1)
+    te = time.perf_counter() - t
+    t = time.perf_counter()
+    lib.so_decompress(np_ptr(out), T, r, np_ptr(back), nb, 1)
+    td = time.perf_counter() - t
+    return {"value": round(nb / (te + td) / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port", "sample": "first 64 MiB of the workload",
+            "encode_gbps": round(nb / te / 1e9, 3), "decode_gbps": round(nb / td / 1e9, 3), "ratio": round(nb / r, 4)}
+
+
+def run_workload(st, torch, src, T, steps, warmup, dist, world):
+    """Returns wall seconds for `steps` round trips (max over ranks), per-direction seconds, kernel ms, csize."""
+    nbytes = src.numel()
+    dst = torch.empty(st.bound(nbytes), dtype=torch.uint8, device=src.device)
+    back = torch.empty_like(src)
+    csize = 0
+
+    def step():
+        nonlocal csize
+        st.compress(src, T, dst, wait=False)
+        csize = st.finish()  # the frame size is a host value the decoder needs
+        idx, _ = st.last_index()
+        st.decompress(dst, T, csize, back, index_ptr=idx, wait=False)
+        st.finish()
+
+    for _ in range(warmup):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    enc_s = dec_s = 0.0
+    kenc = kdec = 0.0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev[0].record()
+        st.compress(src, T, dst, wait=False)
+        csize = st.finish()
+        ev[1].record()
+        idx, _ = st.last_index()
+        st.decompress(dst, T, csize, back, index_ptr=idx, wait=False)
+        st.finish()
+        ev[2].record()
+        ev[2].synchronize()
+        enc_s += ev[0].elapsed_time(ev[1]) / 1e3
+        dec_s += ev[1].elapsed_time(ev[2]) / 1e3
+        kenc += st.kernel_ms(0)
+        kdec += st.kernel_ms(1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=src.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ok = bool(torch.equal(back, src))
+    return dict(wall=wall, enc_s=enc_s, dec_s=dec_s, kenc_ms=kenc / max(steps, 1), kdec_ms=kdec / max(steps, 1), csize=csize, ok=ok)
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from stenos_amd.api import Stenos
+    from stenos_amd.datagen import generate_torch
+
+    T = 4
+    n = int(args.gib * (1 << 30)) // T
+    nbytes = n * T
+    st = Stenos(level=1)
+    st.set_profiling(True)
+
+    src = generate_torch(args.kind, T, n, seed=42, device=f"cuda:{local}", start=rank * n)
+    torch.cuda.synchronize()
+    r = run_workload(st, torch, src, T, args.steps, args.warmup, dist, world)
+    assert r["ok"], "round trip mismatch"
+    total_in = world * nbytes * args.steps
+    value = total_in / r["wall"] / 1e9
+    ratio = nbytes / r["csize"]
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel (encode_blocks): algorithmic bytes = N read + C written per launch
+        algo = nbytes + r["csize"]
+        achieved = algo / (r["kenc_ms"] / 1e3) / 1e9 if r["kenc_ms"] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("encode_blocks_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "encode+decode GB/s (input bytes) at level 1, int32",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(r["wall"] / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.gib:g} GiB int32 per GPU, bytesof=4, level 1, uniform 12-bit values (splitmix64 seed 42, u & 0xFFF)"
+                       if args.kind == "rand12" else f"{args.gib:g} GiB int32 per GPU, kind={args.kind}",
+                       "bytesoftype": T, "level": 1, "superblock_bytes": 131072, "sharding": f"{world} x contiguous superblock ranges"},
+            "compression_ratio": round(ratio, 4),
+            "encode_gbps": round(nbytes * args.steps / r["enc_s"] / 1e9, 3),
+            "decode_gbps": round(nbytes * args.steps / r["dec_s"] / 1e9, 3),
+            "roofline": {"bound": "hbm", "kernel": "encode_blocks", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo, "kernel_ms": round(r["kenc_ms"], 4),
+                         "decode_superblocks": {"achieved": round(algo / (r["kdec_ms"] / 1e3) / 1e9, 2) if r["kdec_ms"] > 0 else 0.0,
+                                                "kernel_ms": round(r["kdec_ms"], 4)}},
+        }
+    # the literal "random int32" variant: every superblock becomes COPY (reported, not the headline)
+    if world == 1:
+        src2 = generate_torch("rand", T, n, seed=42, device=f"cuda:{local}")
+        r2 = run_workload(st, torch, src2, T, max(1, min(3, args.steps)), 1, dist, world)
+        assert r2["ok"]
+        k = max(1, min(3, args.steps))
+        out["full_entropy"] = {"value": round(nbytes * k / r2["wall"] / 1e9, 3), "compression_ratio": round(nbytes / r2["csize"], 5),
+                               "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3)}
+        del src2
+        if not args.no_cpu_baseline:
+            mib = min(args.cpu_sample_mib, nbytes >> 20)
+            sample_bytes = (mib << 20) + 4000 if (mib << 20) + 4000 <= nbytes else nbytes  # not a superblock multiple: the reference decoder rejects those
+            sample = src[:sample_bytes].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample, T, f"first {mib} MiB + 4000 B of the same workload, best of 3")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    st.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

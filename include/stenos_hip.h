@@ -42,6 +42,13 @@ STENOS_EXPORT const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t*
 STENOS_EXPORT size_t stenos_hip_decompress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
 STENOS_EXPORT size_t stenos_hip_decompress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
 
+/* Kernel timing for benchmarks: when enabled, HIP events are recorded on the job's stream around the
+ * dominant kernel of each direction (encode_blocks, decode_superblocks).  stenos_hip_kernel_ms returns the
+ * elapsed milliseconds of the last such launch (which: 0 = encode_blocks, 1 = decode_superblocks), or a
+ * negative value when none was recorded; it waits for the end event. */
+STENOS_EXPORT void stenos_hip_set_profiling(stenos_context* ctx, int enabled);
+STENOS_EXPORT double stenos_hip_kernel_ms(stenos_context* ctx, int which);
+
 #ifdef __cplusplus
 }
 #endif

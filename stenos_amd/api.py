@@ -74,6 +74,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "stenos_hip_last_index": (vp, [vp, ctypes.POINTER(sz)]),
         "stenos_hip_decompress": (sz, [vp, vp, sz, sz, vp, sz, vp, vp]),
         "stenos_hip_decompress_async": (sz, [vp, vp, sz, sz, vp, sz, vp, vp]),
+        "stenos_hip_set_profiling": (None, [vp, c_int]),
+        "stenos_hip_kernel_ms": (ctypes.c_double, [vp, c_int]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
@@ -126,6 +128,13 @@ class Stenos:
 
     def finish(self) -> int:
         return self._check(self.lib.stenos_hip_finish(self.ctx))
+
+    def set_profiling(self, enabled: bool = True):
+        self.lib.stenos_hip_set_profiling(self.ctx, 1 if enabled else 0)
+
+    def kernel_ms(self, which: int) -> float:
+        """elapsed ms of the last encode_blocks (0) / decode_superblocks (1) launch"""
+        return self.lib.stenos_hip_kernel_ms(self.ctx, which)
 
     def last_index(self):
         n = c_size_t(0)

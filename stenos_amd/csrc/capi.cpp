@@ -131,6 +131,10 @@ struct stenos_context_s {
 	size_t job_dst_size = 0, job_expected = 0;
 	bool job_host_codes = false; // the last decode met zstd-based superblocks (finished on the host)
 	size_t last_nsb = 0;
+	// optional kernel timing (stenos_hip_set_profiling)
+	bool profiling = false;
+	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; // encode start/stop, decode start/stop
+	bool ev_valid[2] = { false, false };
 
 	bool device_ready()
 	{
@@ -150,6 +154,18 @@ struct stenos_context_s {
 			b->release();
 		if (h_total)
 			(void)hipHostFree(h_total);
+		for (hipEvent_t e : ev)
+			if (e)
+				(void)hipEventDestroy(e);
+	}
+	void mark(int idx, hipStream_t stream)
+	{
+		if (!profiling)
+			return;
+		if (!ev[idx] && hipEventCreate(&ev[idx]) != hipSuccess)
+			return;
+		if (hipEventRecord(ev[idx], stream) == hipSuccess && (idx & 1))
+			ev_valid[idx >> 1] = true;
 	}
 };
 
@@ -260,8 +276,10 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	const uint32_t init[2] = { 0u, 0xFFFFFFFFu }; // status, first_flagged
 	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	ctx->mark(0, stream);
 	if (level >= 1 && stenos_k_launch_encode(j, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	ctx->mark(1, stream);
 	if (stenos_k_launch_plan(j, stream) != hipSuccess || stenos_k_launch_scan(j, stream) != hipSuccess ||
 	    stenos_k_launch_resolve(j, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
@@ -461,8 +479,10 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 	a.sb_bytes = (uint32_t)fi.sb;
 	a.T = (uint32_t)T;
 	a.status = d_status;
+	ctx->mark(2, stream);
 	if (stenos_k_launch_decode(a, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	ctx->mark(3, stream);
 	if (hipMemcpyAsync((uint8_t*)ctx->h_total + 32, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	ctx->job_kind = 2;
@@ -913,6 +933,17 @@ size_t finish_job(stenos_context_s* ctx)
 } // namespace
 
 extern "C" {
+
+void stenos_hip_set_profiling(stenos_context* ctx, int enabled) { ctx->profiling = enabled != 0; }
+double stenos_hip_kernel_ms(stenos_context* ctx, int which)
+{
+	if (which < 0 || which > 1 || !ctx->ev_valid[which])
+		return -1.0;
+	float ms = 0.f;
+	if (hipEventSynchronize(ctx->ev[2 * which + 1]) != hipSuccess || hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]) != hipSuccess)
+		return -1.0;
+	return (double)ms;
+}
 
 const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb)
 {

@@ -126,14 +126,17 @@ def splitmix64_torch(seed: int, n: int, device, start: int = 0):
     return z ^ _lsr(z, 31)
 
 
-def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25):
-    """Flat uint8 CUDA tensor holding n elements of T bytes; kinds: sorted_i32, rand, rand12, walk, sine."""
+def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25, start: int = 0):
+    """Flat uint8 CUDA tensor holding elements [start, start + n) of the sequence `kind` (T bytes each);
+    kinds: sorted_i32, rand, rand12, walk (start must be 0), sine."""
     import torch
 
     out = torch.empty(n * T, dtype=torch.uint8, device=device)
     carry = 0
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
+    assert start == 0 or kind != "walk"
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        s = s0 + start
         if kind == "sorted_i32":
             v = torch.arange(s, s + m, dtype=torch.int64, device=device).to(torch.int32)
         elif kind == "rand":
@@ -156,5 +159,5 @@ def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chu
             v = x if T == 8 else x.to(torch.float32)
         else:
             raise ValueError(kind)
-        out[s * T:(s + m) * T] = v.contiguous().view(torch.uint8).reshape(-1)
+        out[s0 * T:(s0 + m) * T] = v.contiguous().view(torch.uint8).reshape(-1)
     return out
