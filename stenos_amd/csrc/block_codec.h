@@ -69,20 +69,32 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 // small helpers
 // ------------------------------------------------------------------------------------------------
 
-// the four bytes of plane j owned by this element lane: elements 4l..4l+3
-WV_FN U32 fetch_plane_word(Lds lds, uint32_t in, uint32_t T, uint32_t j)
+// For bytesoftype 4 the lane's four elements (one dword each) stay in registers and the plane words
+// come out of three v_perm_b32 each; other sizes gather the bytes from the LDS copy of the block.
+struct PlaneRegs {
+	U32 w[4];
+	bool valid;
+};
+WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T)
 {
-	U32 l = lane_id();
-	if (T == 4) { // one dword per element
-		U32 a = U32(in) + l * 16u;
-		U32 sh = U32(8u * j);
-		U32 e0 = (lds_ld32(lds, a) >> sh) & 0xFFu;
-		U32 e1 = (lds_ld32(lds, a + 4u) >> sh) & 0xFFu;
-		U32 e2 = (lds_ld32(lds, a + 8u) >> sh) & 0xFFu;
-		U32 e3 = (lds_ld32(lds, a + 12u) >> sh) & 0xFFu;
-		return e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+	PlaneRegs r;
+	r.valid = T == 4;
+	if (r.valid) {
+		U128 e = lds_ld128(lds, U32(in) + lane_id() * 16u);
+		for (uint32_t j = 0; j < 4; ++j) {
+			const uint32_t s2 = 0x0c0c0000u | ((4u + j) << 8) | j; // [lo.bj, hi.bj, 0, 0]
+			U32 p01 = perm_bytes(e.y, e.x, s2), p23 = perm_bytes(e.w, e.z, s2);
+			r.w[j] = perm_bytes(p23, p01, 0x05040100u);
+		}
 	}
-	U32 a = U32(in + j) + l * (4u * T);
+	return r;
+}
+// the four bytes of plane j owned by this element lane: elements 4l..4l+3
+WV_FN U32 fetch_plane_word(Lds lds, uint32_t in, uint32_t T, uint32_t j, const PlaneRegs& regs)
+{
+	if (regs.valid)
+		return j == 0 ? regs.w[0] : (j == 1 ? regs.w[1] : (j == 2 ? regs.w[2] : regs.w[3]));
+	U32 a = U32(in + j) + lane_id() * (4u * T);
 	U32 b0 = lds_ld8(lds, a);
 	U32 b1 = lds_ld8(lds, a + T);
 	U32 b2 = lds_ld8(lds, a + 2u * T);
@@ -139,18 +151,26 @@ WV_FN U32 compact_unflagged(const U32& x, const U32& f)
 
 // Analyse the planes [g, g+np) (np <= 4).  rle: full-block mode (rle + raw override enabled);
 // lines: number of rows that will be emitted (16 for full blocks).
-WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines)
+WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs)
 {
 	const U32 lane = lane_id();
 	// stage 1: element lanes, one plane at a time -> per-row statistics in L.aux
 	for (uint32_t pj = 0; pj < np; ++pj) {
-		PlaneWords p = plane_words(fetch_plane_word(lds, L.in, T, g + pj));
+		U32 w = fetch_plane_word(lds, L.in, T, g + pj, regs);
+		Pred leader = (lane & 3u) == U32(0u);
+		U32 addr = U32(L.aux + pj * 128u) + (lane >> 2) * 8u;
+		const uint32_t first = readlane(w, 0) & 0xFFu;
+		if (!any(w != U32(first * 0x01010101u))) {
+			// all 256 bytes equal (block_compress.h:396, 406, 415-418): statistics of a constant plane, nothing to measure
+			lds_st32(lds, addr, U32((first ^ 0x80u) * 0x0101u), leader);
+			lds_st32(lds, addr + 4u, U32(0u), leader);
+			continue;
+		}
+		PlaneWords p = plane_words(w);
 		U32 cnt = quad_add(popc(p.z1) | (popc(p.z2) << 16));
 		U32 s = p.w ^ 0x80808080u, ds = p.dw ^ 0x80808080u; // signed order (:407-411)
 		U32 mn = quad_min(min4(s)), mx = quad_max(max4(s));
 		U32 dmn = quad_min(min4(ds)), dmx = quad_max(max4(ds));
-		Pred leader = (lane & 3u) == U32(0u);
-		U32 addr = U32(L.aux + pj * 128u) + (lane >> 2) * 8u;
 		lds_st32(lds, addr, mn | (mx << 8) | (dmn << 16) | (dmx << 24), leader);
 		lds_st32(lds, addr + 4u, cnt, leader);
 	}
@@ -264,7 +284,7 @@ WV_FN uint32_t plane_offsets(Lds lds, const Layout& L, uint32_t T, bool full_blo
 }
 
 // Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
-WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines)
+WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs)
 {
 	const U32 lane = lane_id();
 	Lds out = lds + L.out;
@@ -307,7 +327,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		uint32_t pbase = base + (pi >> 8);
 		if (type == PLANE_SAME)
 			continue;
-		PlaneWords p = plane_words(fetch_plane_word(lds, L.in, T, j));
+		PlaneWords p = plane_words(fetch_plane_word(lds, L.in, T, j, regs));
 		if (type == PLANE_RAW) {
 			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, p.w, pred_all(true));
 			continue;
@@ -346,12 +366,14 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 	wave_sync();
 }
 
-// zero `bytes` (multiple of 4) of LDS at `off`
+// zero `bytes` (multiple of 16, 16-byte aligned) of LDS at `off`
 WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
 {
 	const U32 lane = lane_id();
-	for (uint32_t o = 0; o < bytes; o += 256)
-		lds_st32(lds, U32(off + o) + lane * 4u, U32(0u), (U32(o) + lane * 4u) < U32(bytes));
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	for (uint32_t o = 0; o < bytes; o += 1024)
+		lds_st128(lds, U32(off + o) + lane * 16u, z, (U32(o) + lane * 16u) < U32(bytes));
 	wave_sync();
 }
 
@@ -414,6 +436,13 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		return has & (((word >> (gidx & 31u)) & 1u) == U32(1u));
 	};
 
+	// ---- pass 1: chain[pos] = nearest earlier position with the same hash (what the table would hold if
+	// no group were skipped).  After the chunk that contains the early-stop group a lower bound of the
+	// bytes produced up to that group decides most failing attempts without running the state machine.
+	const uint32_t gq = quarter / 8 + 1;     // first group whose start index exceeds count/4
+	const uint32_t nq = 8 * (gq + 1);        // values covered up to and including that group
+	const uint32_t cq = (nq - 1) / 64;       // chunk that holds its last value
+	uint32_t matchable = 0;                  // positions < nq that have any same-hash predecessor
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const U32 pos = U32(c * 64u) + lane;
 		LzVal v = lz_value(lds, L.in, B, pos);
@@ -436,15 +465,31 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		U32 tabv = lds_ld32(lds, U32(tab) + key * 4u);
 		U32 H = sel(has_intra, U32(c * 64u) + intra, tabv);
 		lds_st32(lds, U32(chain) + pos * 4u, H, pred_all(true));
-		// the last lane of each class records its position (the table only matters for later chunks;
-		// positions of groups skipped below are jumped over through the chain)
+		// the last lane of each class records its position (positions of groups that turn out to be
+		// skipped are jumped over through the chain)
 		U32 hmask = ~((U32(2u) << (lane & 31u)) - 1u);
 		hmask = sel((lane & 31u) == U32(31u), U32(0u), hmask);
 		U32 above_lo = sel(lane < U32(32u), cls_lo & hmask, U32(0u));
 		U32 above_hi = sel(lane < U32(32u), cls_hi, cls_hi & hmask);
 		lds_st32(lds, U32(tab) + key * 4u, pos, (above_lo | above_hi) == U32(0u));
 		wave_sync();
+		if (c <= cq) {
+			matchable += (uint32_t)__builtin_popcountll(ballot((H != U32(LZ_NONE)) & (pos < U32(nq))));
+			if (c == cq) {
+				// every value costs B bytes unless it matches (>= 1 byte), and only values with a same-hash
+				// predecessor can match; each group adds its flag byte (lz_compress.h:203-219)
+				const uint32_t lower = (gq + 1) + nq * B - matchable * (B - 1);
+				if (lower > max_size || (double)lower > (double)max_size * 0.4)
+					return 0; // the reference fails at :221-223 or :224-229 with at least this many bytes
+			}
+		}
+	}
 
+	// ---- pass 2: the groups in order
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const U32 pos = U32(c * 64u) + lane;
+		LzVal v = lz_value(lds, L.in, B, pos);
+		U32 H = lds_ld32(lds, U32(chain) + pos * 4u);
 		// current candidate: follow the chain over groups that were skipped (not hashed)
 		for (;;) {
 			Pred s = skipped(H);
@@ -537,8 +582,9 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
 {
 	lds_zero(lds, L.out, out_capacity(T));
+	const PlaneRegs regs = load_plane_regs(lds, L.in, T);
 	for (uint32_t g = 0; g < T; g += 4)
-		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16);
+		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs);
 	uint32_t need;
 	uint32_t full = plane_offsets(lds, L, T, true, 16, &need);
 	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
@@ -553,7 +599,7 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 		}
 		// nothing was written to the image on failure
 	}
-	emit_planes(lds, L, T, 0, 16);
+	emit_planes(lds, L, T, 0, 16, regs);
 	r.size = header_bytes(T) + full;
 	return r;
 }
@@ -571,11 +617,12 @@ WV_FN uint32_t encode_partial_lines(Lds lds, const Layout& L, uint32_t T, uint32
 		wave_sync();
 		return 1;
 	}
+	const PlaneRegs regs = load_plane_regs(lds, L.in, T);
 	for (uint32_t g = 0; g < T; g += 4)
-		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines);
+		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines, regs);
 	uint32_t pneed;
 	uint32_t full = plane_offsets(lds, L, T, false, lines, &pneed);
-	emit_planes(lds, L, T, 1, lines);
+	emit_planes(lds, L, T, 1, lines, regs);
 	if (1 + pneed > *need)
 		*need = 1 + pneed;
 	return 1 + header_bytes(T) + full;

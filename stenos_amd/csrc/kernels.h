@@ -24,6 +24,8 @@ struct DecodeArgs {
 	uint32_t* status;
 };
 
+uint32_t stenos_k_cu_count();
+uint32_t stenos_k_waves_per_cu(size_t lds_bytes);
 size_t stenos_k_encode_lds_bytes(uint32_t T);
 size_t stenos_k_decode_lds_bytes(uint32_t T);
 uint32_t stenos_k_slot_stride(uint32_t T);

@@ -141,6 +141,22 @@ WV_FN U32 mulhi(const U32& a, const U32& b)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(((uint64_t)a.l[i] * b.l[i]) >> 32);
 	return r;
 }
+// v_perm_b32: result byte i = byte (sel byte i) of the 8 bytes {hi:lo}; selector 0x0c gives 0
+WV_FN U32 perm_bytes(const U32& hi, const U32& lo, uint32_t selw)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint64_t both = ((uint64_t)hi.l[i] << 32) | lo.l[i];
+		uint32_t v = 0;
+		for (int k = 0; k < 4; ++k) {
+			uint32_t sb = (selw >> (8 * k)) & 0xFF;
+			uint32_t byte = sb < 8 ? (uint32_t)((both >> (8 * sb)) & 0xFF) : 0u;
+			v |= byte << (8 * k);
+		}
+		r.l[i] = v;
+	}
+	return r;
+}
 WV_FN uint64_t ballot(const Pred& p)
 {
 	uint64_t m = 0;
@@ -332,16 +348,36 @@ WV_FN U32 umax(U32 a, U32 b) { return a > b ? a : b; }
 WV_FN U32 popc(U32 a) { return (U32)__builtin_popcount(a); }
 WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
 WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
+WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __ballot(p); }
 WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }
 WV_FN U32 shfl(U32 a, U32 src) { return (U32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)a); }
-WV_FN U32 shfl_up(U32 a, uint32_t n, uint32_t fill)
+// generic forms (LDS crossbar); the shapes the codec uses most have DPP forms below
+WV_FN U32 shfl_up_any(U32 a, uint32_t n, uint32_t fill)
 {
 	U32 l = lane_id();
 	U32 v = (U32)__builtin_amdgcn_ds_bpermute((int)((l - n) << 2), (int)a);
 	return l >= n ? v : fill;
 }
-WV_FN U32 shfl_xor(U32 a, uint32_t m) { return (U32)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)a); }
+WV_FN U32 shfl_xor_any(U32 a, uint32_t m) { return (U32)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)a); }
+// lane i reads a[i - n]; lanes < n read `fill`.  n == 1 is one DPP wave_shr:1 (gfx9: ctrl 0x138).
+WV_FN U32 shfl_up(U32 a, uint32_t n, uint32_t fill)
+{
+	if (__builtin_constant_p(n) && n == 1)
+		return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)a, 0x138, 0xf, 0xf, false);
+	return shfl_up_any(a, n, fill);
+}
+// lane i reads a[i ^ m]; m = 1, 2 are DPP quad_perm [1,0,3,2] (0xB1) and [2,3,0,1] (0x4E)
+WV_FN U32 shfl_xor(U32 a, uint32_t m)
+{
+	if (__builtin_constant_p(m) && m == 1)
+		return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, false);
+	if (__builtin_constant_p(m) && m == 2)
+		return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, false);
+	if (__builtin_constant_p(m) && m == 8)
+		return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0x128, 0xf, 0xf, false); // row_ror:8
+	return shfl_xor_any(a, m);
+}
 
 // DPP controls (gfx9): row_shr:n = 0x110+n, row_ror:n = 0x120+n
 template <int CTRL>
@@ -367,6 +403,8 @@ WV_FN U32 row_shr(U32 a, uint32_t n, uint32_t fill)
 		case 4: v = dpp_zero<0x114>(a); break;
 		default: v = dpp_zero<0x118>(a); break;
 	}
+	if (__builtin_constant_p(fill) && fill == 0)
+		return v; // lanes without a source already read 0
 	return (lane_id() & 15u) >= n ? v : fill;
 }
 // orders this wave's LDS accesses (program order is enough for one wave on the hardware; this
@@ -393,9 +431,11 @@ WV_FN void lds_st8(Lds m, U32 a, U32 v, Pred p)
 {
 	if (p) m[a] = (uint8_t)v;
 }
+// OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
+// at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)
 WV_FN void lds_or32(Lds m, U32 a, U32 v, Pred p)
 {
-	if (p) __hip_atomic_fetch_or((uint32_t*)(m + (a & ~3u)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	__hip_atomic_fetch_or((uint32_t*)(m + (p ? (a & ~3u) : lane_id() * 4u)), p ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // ---- global memory ----
@@ -483,7 +523,7 @@ WV_FN void lds_put_bits(Lds m, const U32& bitpos, const U32& value, const Pred& 
 	U32 sh = bitpos & 31u;
 	lds_or32(m, addr, value << sh, p);
 	U32 hi = sel(sh == U32(0u), U32(0u), value >> (U32(32u) - sh));
-	lds_or32(m, addr + 4u, hi, p & (hi != U32(0u)));
+	lds_or32(m, addr + 4u, hi, p); // hi == 0 ORs nothing; the image has 4 bytes of slack
 }
 
 // all-reduce inside each aligned group of 4 lanes
@@ -520,6 +560,7 @@ WV_FN U32 row_excl_scan(const U32& x)
 	s = s + row_shr(s, 8, 0);
 	return s - x;
 }
+#ifdef WV_HOST_EMULATION
 // maximum over the 64 lanes (uniform result)
 WV_FN uint32_t wave_max(U32 x)
 {
@@ -541,6 +582,31 @@ WV_FN U32 wave_incl_scan(U32 s)
 	s = s + shfl_up(s, 16, 0);
 	return s + shfl_up(s, 32, 0);
 }
+#else
+// gfx9 DPP forms: reductions inside the 16-lane rows, then four readlanes
+WV_FN uint32_t wave_max(U32 x)
+{
+	x = umax(x, row_ror(x, 8));
+	x = umax(x, row_ror(x, 4));
+	x = umax(x, row_ror(x, 2));
+	x = umax(x, row_ror(x, 1));
+	uint32_t a = readlane(x, 0), b = readlane(x, 16), c = readlane(x, 32), d = readlane(x, 48);
+	a = a > b ? a : b;
+	c = c > d ? c : d;
+	return a > c ? a : c;
+}
+// row_shr 1,2,4,8 with zero fill, then row_bcast:15 (0x142, rows 1 and 3) and row_bcast:31 (0x143, rows 2 and 3)
+WV_FN U32 wave_incl_scan(U32 s)
+{
+	s += dpp_zero<0x111>(s);
+	s += dpp_zero<0x112>(s);
+	s += dpp_zero<0x114>(s);
+	s += dpp_zero<0x118>(s);
+	s += (U32)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false);
+	s += (U32)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);
+	return s;
+}
+#endif
 
 // ---- SWAR on four packed bytes ----
 WV_FN U32 bytes_sub(const U32& a, const U32& b) // per-byte a - b (mod 256)
