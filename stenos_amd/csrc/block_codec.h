@@ -319,7 +319,8 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		// SAME: the plane's byte; every row has mx == mn so minv is that byte (:747-750)
 		lds_put_bits(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
 	}
-	// element lanes: row payloads
+	// element lanes: row payloads.  Every lane contributes one piece per plane (its 4 raw bytes, its 4
+	// packed values or its rle literals); rle rows add their 4 mask bits.
 	const U32 row = lane >> 2, q = lane & 3u;
 	for (uint32_t j = 0; j < T; ++j) {
 		uint32_t pi = readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
@@ -327,41 +328,42 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		uint32_t pbase = base + (pi >> 8);
 		if (type == PLANE_SAME)
 			continue;
-		PlaneWords p = plane_words(fetch_plane_word(lds, L.in, T, j, regs));
+		U32 w = fetch_plane_word(lds, L.in, T, j, regs);
 		if (type == PLANE_RAW) {
-			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, p.w, pred_all(true));
+			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, w, pred_all(true));
 			continue;
 		}
 		U32 lo = lds_ld32(lds, U32(L.rowinfo + j * 128u) + row * 8u);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
 		U32 rbase = U32(pbase) + (lo >> 16);
 		Pred act = row < U32(lines);
-		// raw row (:674-676)
-		lds_put_bits(out, (rbase + q * 4u) * 8u, p.w, act & (hdr == U32(15u)));
-		// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
-		{
-			Pred is7 = hdr == U32(7u), is6 = hdr == U32(6u);
-			Pred isr = act & (is7 | is6);
-			if (any(isr)) {
-				U32 f = zero_mask_to_bits(sel(is7, p.z1, p.z2));
-				U32 src = sel(is7, p.w, p.dw);
-				U32 nlit = U32(4u) - popc(f);
-				U32 before = quad_add(sel(isr, nlit << (q << 3), U32(0u))); // per-lane literal counts of the quad
-				U32 prior = (before & ((U32(1u) << (q << 3)) - 1u));
-				prior = (prior & 0xFFu) + ((prior >> 8) & 0xFFu) + ((prior >> 16) & 0xFFu);
-				lds_put_bits(out, rbase * 8u + q * 4u, f, isr);
-				lds_put_bits(out, (rbase + 2u + prior) * 8u, compact_unflagged(src, f), isr & (nlit != U32(0u)));
-			}
-		}
+		// deltas against the previous byte in plane order, 0 before the plane (block_compress.h:399-401)
+		U32 dw = bytes_sub(w, (w << 8) | (shfl_up(w, 1, 0) >> 24));
+		Pred is15 = hdr == U32(15u), is7 = hdr == U32(7u), is6 = hdr == U32(6u);
 		// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each
-		{
-			U32 bits = hdr & 7u;
-			Pred isp = act & (hdr != U32(15u)) & (hdr != U32(7u)) & (hdr != U32(6u)) & (bits != U32(0u));
-			U32 v = bytes_sub(sel(hdr < U32(8u), p.w, p.dw), bytes_splat(minv));
-			U32 x = byte_of(v, 0) | (byte_of(v, 1) << bits) | (byte_of(v, 2) << (bits * 2u)) | (byte_of(v, 3) << (bits * 3u));
-			U32 bitpos = (rbase + (q >> 1) * bits) * 8u + (q & 1u) * bits * 4u;
-			lds_put_bits(out, bitpos, x, isp);
+		U32 bits = hdr & 7u;
+		U32 v = bytes_sub(sel(hdr < U32(8u), w, dw), bytes_splat(minv));
+		U32 x = byte_of(v, 0) | (byte_of(v, 1) << bits) | (byte_of(v, 2) << (bits * 2u)) | (byte_of(v, 3) << (bits * 3u));
+		U32 piece = sel(is15, w, x); // raw row (:674-676): the 4 bytes as they are
+		U32 bitpos = sel(is15, (rbase + q * 4u) * 8u, (rbase + (q >> 1) * bits) * 8u + (q & 1u) * bits * 4u);
+		Pred emit = act & (is15 | (!is7 & !is6 & (bits != U32(0u))));
+		// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
+		Pred isr = act & (is7 | is6);
+		if (any(isr)) {
+			U32 z1 = bytes_zero_mask(dw); // byte == previous byte (:268-275)
+			U32 pd = sel(q == U32(0u), U32(0u), shfl_up(dw, 1, 0) >> 24);
+			U32 z2 = bytes_zero_mask(dw ^ ((dw << 8) | pd)); // delta == previous delta, 0 before the row (:248-255)
+			U32 f = zero_mask_to_bits(sel(is7, z1, z2));
+			U32 nlit = U32(4u) - popc(f);
+			U32 before = quad_add(sel(isr, nlit << (q << 3), U32(0u))); // literal counts of the quad's lanes
+			U32 prior = (before & ((U32(1u) << (q << 3)) - 1u));
+			prior = (prior & 0xFFu) + ((prior >> 8) & 0xFFu) + ((prior >> 16) & 0xFFu);
+			lds_put_bits(out, rbase * 8u + q * 4u, f, isr);
+			piece = sel(isr, compact_unflagged(sel(is7, w, dw), f), piece);
+			bitpos = sel(isr, (rbase + 2u + prior) * 8u, bitpos);
+			emit = emit | (isr & (nlit != U32(0u)));
 		}
+		lds_put_bits(out, bitpos, piece, emit);
 	}
 	wave_sync();
 }
@@ -418,9 +420,39 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	const uint32_t tab = L.lz, chain = L.lz + 1024, cur = chain + count * 4;
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
 
+	const uint32_t gq = quarter / 8 + 1; // first group whose start index exceeds count/4: the early-stop test runs after it
+	const uint32_t nq = 8 * (gq + 1);    // values covered up to and including that group
+	const uint32_t cq = (nq - 1) / 64;   // chunk that holds its last value
+	{
+		// Cheap rejection of hopeless attempts (most of them).  Every value costs B bytes unless it matches
+		// (>= 1 byte) and only values with an earlier same-hash value can match; each group adds its flag
+		// byte (lz_compress.h:203-219).  Counting the distinct hash keys among the first nq values gives a
+		// lower bound of the bytes produced when the reference runs its early-stop test; if even that bound
+		// fails the test (:221-229) the attempt is over without building the chains.
+		U128 z;
+		z.x = z.y = z.z = z.w = U32(0u);
+		lds_st128(lds, U32(tab) + lane * 16u, z, pred_all(true)); // 256 counters
+		wave_sync();
+		uint32_t distinct = 0;
+		for (uint32_t c = 0; c <= cq; ++c) {
+			const U32 pos = U32(c * 64u) + lane;
+			Pred in = pos < U32(nq);
+			U32 key = lz_hash(lz_value(lds, L.in, B, sel(in, pos, U32(0u))), B);
+			U32 old = lds_add_rtn32(lds, U32(tab) + key * 4u, U32(1u), in);
+			distinct += (uint32_t)__builtin_popcountll(ballot(in & (old == U32(0u))));
+		}
+		wave_sync();
+		const uint32_t lower = (gq + 1) + nq * B - (nq - distinct) * (B - 1);
+		if (lower > max_size || (double)lower > (double)max_size * 0.4)
+			return 0;
+	}
+
 	// empty table: every entry "no position"
-	for (uint32_t o = 0; o < 1024; o += 256)
-		lds_st32(lds, U32(tab + o) + lane * 4u, U32(LZ_NONE), pred_all(true));
+	{
+		U128 none;
+		none.x = none.y = none.z = none.w = U32(LZ_NONE);
+		lds_st128(lds, U32(tab) + lane * 16u, none, pred_all(true));
+	}
 	wave_sync();
 
 	uint32_t failed = 0, max_failed = 3, produced = 0;
@@ -437,12 +469,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	};
 
 	// ---- pass 1: chain[pos] = nearest earlier position with the same hash (what the table would hold if
-	// no group were skipped).  After the chunk that contains the early-stop group a lower bound of the
-	// bytes produced up to that group decides most failing attempts without running the state machine.
-	const uint32_t gq = quarter / 8 + 1;     // first group whose start index exceeds count/4
-	const uint32_t nq = 8 * (gq + 1);        // values covered up to and including that group
-	const uint32_t cq = (nq - 1) / 64;       // chunk that holds its last value
-	uint32_t matchable = 0;                  // positions < nq that have any same-hash predecessor
+	// no group were skipped)
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const U32 pos = U32(c * 64u) + lane;
 		LzVal v = lz_value(lds, L.in, B, pos);
@@ -473,16 +500,6 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		U32 above_hi = sel(lane < U32(32u), cls_hi, cls_hi & hmask);
 		lds_st32(lds, U32(tab) + key * 4u, pos, (above_lo | above_hi) == U32(0u));
 		wave_sync();
-		if (c <= cq) {
-			matchable += (uint32_t)__builtin_popcountll(ballot((H != U32(LZ_NONE)) & (pos < U32(nq))));
-			if (c == cq) {
-				// every value costs B bytes unless it matches (>= 1 byte), and only values with a same-hash
-				// predecessor can match; each group adds its flag byte (lz_compress.h:203-219)
-				const uint32_t lower = (gq + 1) + nq * B - matchable * (B - 1);
-				if (lower > max_size || (double)lower > (double)max_size * 0.4)
-					return 0; // the reference fails at :221-223 or :224-229 with at least this many bytes
-			}
-		}
 	}
 
 	// ---- pass 2: the groups in order

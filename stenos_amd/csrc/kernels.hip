@@ -8,7 +8,7 @@
 //   scan_superblocks   exclusive scan of the superblock sizes -> byte offset of every superblock header
 //   resolve_frame      one wavefront: exact replay of the reference's capacity rules for the superblocks
 //                      the plan flagged (normally none or the last; pipeline.h)
-//   pack_frame         one wavefront per block: [code][csize:3] headers, block payloads or raw copy,
+//   pack_frame         one wavefront per 32 blocks: [code][csize:3] headers, block payloads or raw copy,
 //                      frame header (stenos.cpp:862-874)
 // Decode pipeline:
 //   walk_superblocks   (only without an index) serial walk of the [code][csize:3] chain (stenos.cpp:1129-1134)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void resolve_frame(FrameJob j)
 	resolve_capacity(g_lds, L, j);
 }
 
-__global__ __launch_bounds__(64) void pack_frame(FrameJob j) { pack_block(j, blockIdx.x); }
+__global__ __launch_bounds__(64) void pack_frame(FrameJob j, uint32_t wps) { pack_blocks(j, blockIdx.x / wps, blockIdx.x % wps); }
 
 // Serial walk of the superblock chain by one lane: off[s] = byte offset of superblock s's header.
 __global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* __restrict__ off,
@@ -246,8 +246,8 @@ hipError_t stenos_k_launch_resolve(const FrameJob& j, hipStream_t stream)
 
 hipError_t stenos_k_launch_pack(const FrameJob& j, hipStream_t stream)
 {
-	const uint64_t nblocks = j.nfull + (j.tail_bytes ? 1 : 0);
-	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)nblocks), dim3(64), 0, stream, j);
+	const uint32_t wps = pack_waves_per_superblock(j.bps);
+	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)(j.nsb * wps)), dim3(64), 0, stream, j, wps);
 	return hipGetLastError();
 }
 

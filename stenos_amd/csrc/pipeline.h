@@ -188,8 +188,13 @@ WV_FN void resolve_capacity(Lds lds, const Layout& L, const FrameJob& j)
 	gstore_uniform64(j.total, off);
 }
 
-// One wavefront per block (tail block last): headers + payload into the frame.
-WV_FN void pack_block(const FrameJob& j, uint64_t b)
+// Blocks handed to one wavefront of the pack step: their offsets and sizes are fetched with one vector
+// load and the copies of consecutive blocks overlap in the memory system.
+constexpr uint32_t PACK_BLOCKS = 32;
+WV_HD uint32_t pack_waves_per_superblock(uint32_t bps) { return (bps + 1 + PACK_BLOCKS - 1) / PACK_BLOCKS; }
+
+// Wavefront `w` of superblock `s`: headers + payload of blocks [w*PACK_BLOCKS, ...) into the frame.
+WV_FN void pack_blocks(const FrameJob& j, uint64_t s, uint32_t w)
 {
 	const U32 lane = lane_id();
 	if (gload_uniform(j.status))
@@ -197,32 +202,41 @@ WV_FN void pack_block(const FrameJob& j, uint64_t b)
 	const uint64_t total = gload_uniform64(j.total);
 	if (total > j.dst_size) // never write past the caller's buffer; the host reports DST_OVERFLOW
 		return;
-	const bool is_tail = b >= j.nfull;
-	const uint64_t s = is_tail ? j.nsb - 1 : b / j.bps;
+	const uint32_t count = superblock_blocks(j, s);
+	const uint32_t k0 = w * PACK_BLOCKS;
+	if (k0 >= count)
+		return;
+	const uint32_t k1 = k0 + PACK_BLOCKS < count ? k0 + PACK_BLOCKS : count;
 	const uint64_t first = s * j.bps;
+	const bool has_tail = s == j.nsb - 1 && j.tail_bytes;
 	uint8_t* base = j.dst + gload_uniform64(j.sb_off + s);
 	const uint32_t code = gload_uniform8(j.sb_code + s);
 	const uint32_t csize = gload_uniform(j.sb_csize + s);
-	if (b == 0 && j.shift_byte != 0xFFFFFFFFu) { // frame header: [shift][bytes:7 LE] (+ [superblock size:4 LE]), stenos.cpp:862-874
+	if (s == 0 && w == 0 && j.shift_byte != 0xFFFFFFFFu) { // frame header: [shift][bytes:7 LE] (+ [superblock size:4 LE]), stenos.cpp:862-874
 		const uint64_t v = (uint64_t)j.shift_byte | (j.total_bytes << 8);
 		gst8(j.dst, lane, (U32((uint32_t)v) >> ((lane & 3u) << 3)), lane < U32(4u));
 		gst8(j.dst, lane, (U32((uint32_t)(v >> 32)) >> ((lane & 3u) << 3)), (lane >= U32(4u)) & (lane < U32(8u)));
 		if (j.shift_byte == 255)
 			gst8(j.dst + 8, lane, U32(j.sb_bytes) >> ((lane & 3u) << 3), lane < U32(4u));
 	}
-	if (b == first || (is_tail && j.nfull == first)) // superblock header [code][csize:3 LE] (stenos.cpp:613-615)
+	if (w == 0) // superblock header [code][csize:3 LE] (stenos.cpp:613-615)
 		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
-	const bool overridden = j.tiny_last && s == j.nsb - 1;
-	if (overridden) {
-		if (is_tail) // payload prepared by the host (zstd or raw bytes)
-			copy_g2g(base + 4, j.override_payload, csize);
+	if (j.tiny_last && s == j.nsb - 1) { // payload prepared by the host (zstd or raw bytes)
+		copy_g2g(base + 4, j.override_payload, csize);
+		return;
 	}
-	else if (code == 1)
-		copy_g2g(base + 4 + gload_uniform(j.boff + b), j.slots + b * (uint64_t)j.slot_stride, gload_uniform(j.bsize + b));
-	else { // copy superblock: raw input bytes
-		const uint32_t bs = 256 * j.T;
-		copy_g2g(base + 4 + (uint64_t)(b - first) * bs, j.src + b * (uint64_t)bs, is_tail ? j.tail_bytes : bs);
+	const uint32_t bs = 256 * j.T;
+	if (code != 1) { // copy superblock: the raw input bytes of these blocks in one piece
+		const uint64_t begin = (uint64_t)k0 * bs;
+		const uint64_t end = (has_tail && k1 == count) ? (uint64_t)(count - 1) * bs + j.tail_bytes : (uint64_t)k1 * bs;
+		copy_g2g(base + 4 + begin, j.src + first * (uint64_t)bs + begin, (uint32_t)(end - begin));
+		return;
 	}
+	Pred mine = (U32(k0) + lane) < U32(k1);
+	U32 offs = gld32((const uint8_t*)(j.boff + first + k0), lane * 4u, mine);
+	U32 sizes = gld32((const uint8_t*)(j.bsize + first + k0), lane * 4u, mine);
+	for (uint32_t k = k0; k < k1; ++k)
+		copy_g2g(base + 4 + readlane(offs, k - k0), j.slots + (first + k) * (uint64_t)j.slot_stride, readlane(sizes, k - k0));
 }
 
 } // namespace codec

@@ -231,6 +231,20 @@ WV_FN void lds_st8(Lds m, const U32& a, const U32& v, const Pred& p)
 	for (int i = 0; i < WAVE; ++i)
 		if (p.l[i]) m[a.l[i]] = (uint8_t)v.l[i];
 }
+// atomic add returning the previous value (lane order on the host; any order is a valid device order)
+WV_FN U32 lds_add_rtn32(Lds m, const U32& a, const U32& v, const Pred& p)
+{
+	U32 r(0u);
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			uint32_t t;
+			memcpy(&t, m + (a.l[i] & ~3u), 4);
+			r.l[i] = t;
+			t += v.l[i];
+			memcpy(m + (a.l[i] & ~3u), &t, 4);
+		}
+	return r;
+}
 WV_FN void lds_or32(Lds m, const U32& a, const U32& v, const Pred& p)
 {
 	for (int i = 0; i < WAVE; ++i)
@@ -430,6 +444,10 @@ WV_FN void lds_st32(Lds m, U32 a, U32 v, Pred p)
 WV_FN void lds_st8(Lds m, U32 a, U32 v, Pred p)
 {
 	if (p) m[a] = (uint8_t)v;
+}
+WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
+{
+	return p ? __hip_atomic_fetch_add((uint32_t*)(m + (a & ~3u)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
 }
 // OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
 // at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)

@@ -194,8 +194,10 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 		}
 	}
 	if (!result) {
-		for (uint64_t b = 0; b < nblocks; ++b) // pack_frame
-			pack_block(j, b);
+		const uint32_t wps = pack_waves_per_superblock(j.bps);
+		for (uint64_t s = 0; s < j.nsb; ++s) // pack_frame
+			for (uint32_t w = 0; w < wps; ++w)
+				pack_blocks(j, s, w);
 		if (status || total > dst_size)
 			result = ERR_DST;
 		else {
