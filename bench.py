@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--gib", type=float, default=8.0, help="input GiB per GPU (default: the 8 GiB of configs[1])")
     p.add_argument("--kind", default="rand12", help="datagen kind for the headline workload")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-full-entropy", action="store_true", help="skip the extra full-entropy (all COPY) measurement")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
     return p.parse_args()
 
@@ -212,7 +213,7 @@ def main():
                                                 "kernel_ms": round(r["kdec_ms"], 4)}},
         }
     # the literal "random int32" variant: every superblock becomes COPY (reported, not the headline)
-    if world == 1:
+    if world == 1 and not args.no_full_entropy:
         src2 = generate_torch("rand", T, n, seed=42, device=f"cuda:{local}")
         r2 = run_workload(st, torch, src2, T, max(1, min(3, args.steps)), 1, dist, world)
         assert r2["ok"]
@@ -220,6 +221,7 @@ def main():
         out["full_entropy"] = {"value": round(nbytes * k / r2["wall"] / 1e9, 3), "compression_ratio": round(nbytes / r2["csize"], 5),
                                "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3)}
         del src2
+    if world == 1:
         if not args.no_cpu_baseline:
             mib = min(args.cpu_sample_mib, nbytes >> 20)
             sample_bytes = (mib << 20) + 4000 if (mib << 20) + 4000 <= nbytes else nbytes  # not a superblock multiple: the reference decoder rejects those

@@ -34,6 +34,7 @@ struct Layout {
 	uint32_t aux;     // 64 entries of 8 bytes (row statistics of the current plane group) / decoder scratch
 	uint32_t lz;      // mini-LZ: table 256*4 + chain count*4 + cur count*4
 	uint32_t total;
+	uint32_t dbg;     // diagnostics only (STENOS_DEBUG_PHASES): 1 = no LZ attempt, 2 = no emission, 4 = no analysis
 };
 
 WV_HD uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -62,6 +63,7 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 		o += 256 * 4 + count * 8;
 	}
 	L.total = align16(o);
+	L.dbg = 0;
 	return L;
 }
 
@@ -447,6 +449,43 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 			return 0;
 	}
 
+	{
+		// Second rejection test, for data whose values hardly repeat (floats, noise): a value can only match
+		// when an equal value precedes it, so with `dups` = values that have an equal predecessor the whole
+		// stream takes at least ngroups + count*B - dups*(B-1) bytes; above max_size the reference fails
+		// (lz_compress.h:221-223) after doing all the work.  Distinct values are counted with an
+		// open-addressing table of positions (2*count slots in the chain/candidate area, linear probing,
+		// LDS compare-and-swap).
+		const uint32_t slots = 2 * count;
+		for (uint32_t o = 0; o < slots * 4; o += 1024) {
+			U128 none;
+			none.x = none.y = none.z = none.w = U32(LZ_NONE);
+			lds_st128(lds, U32(chain + o) + lane * 16u, none, (U32(o) + lane * 16u) < U32(slots * 4));
+		}
+		wave_sync();
+		uint32_t dups = 0;
+		for (uint32_t c = 0; c < nchunks; ++c) {
+			const U32 pos = U32(c * 64u) + lane;
+			LzVal v = lz_value(lds, L.in, B, pos);
+			U32 h = mulhi((v.lo ^ (v.hi * 0x9E3779B1u)) * 0x85EBCA6Bu, U32(slots));
+			Pred todo = pred_all(true);
+			Pred dup = pred_all(false);
+			while (any(todo)) {
+				U32 found = lds_cas32(lds, U32(chain) + h * 4u, U32(LZ_NONE), pos, todo);
+				Pred occupied = todo & (found != U32(LZ_NONE));
+				LzVal o = lz_value(lds, L.in, B, sel(occupied, found, U32(0u)));
+				Pred same = occupied & (o.lo == v.lo) & (o.hi == v.hi);
+				dup = dup | same;
+				todo = occupied & !same; // inserted or duplicate: done; different value: next slot
+				h = sel(h + 1u == U32(slots), U32(0u), h + 1u);
+			}
+			dups += (uint32_t)__builtin_popcountll(ballot(dup));
+		}
+		wave_sync();
+		if (count / 8 + count * B - dups * (B - 1) > max_size)
+			return 0;
+	}
+
 	// empty table: every entry "no position"
 	{
 		U128 none;
@@ -600,14 +639,15 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 {
 	lds_zero(lds, L.out, out_capacity(T));
 	const PlaneRegs regs = load_plane_regs(lds, L.in, T);
-	for (uint32_t g = 0; g < T; g += 4)
-		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs);
+	if (!(L.dbg & 4u))
+		for (uint32_t g = 0; g < T; g += 4)
+			analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs);
 	uint32_t need;
 	uint32_t full = plane_offsets(lds, L, T, true, 16, &need);
 	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
 	BlockInfo r;
 	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
-	if (allow_lz && eligible) {
+	if (allow_lz && eligible && !(L.dbg & 1u)) {
 		uint32_t n = lz_try(lds, L, T, full, 0);
 		if (n) {
 			r.size = n + 1;
@@ -616,7 +656,8 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 		}
 		// nothing was written to the image on failure
 	}
-	emit_planes(lds, L, T, 0, 16, regs);
+	if (!(L.dbg & 2u))
+		emit_planes(lds, L, T, 0, 16, regs);
 	r.size = header_bytes(T) + full;
 	return r;
 }

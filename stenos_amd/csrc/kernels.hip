@@ -8,7 +8,7 @@
 //   scan_superblocks   exclusive scan of the superblock sizes -> byte offset of every superblock header
 //   resolve_frame      one wavefront: exact replay of the reference's capacity rules for the superblocks
 //                      the plan flagged (normally none or the last; pipeline.h)
-//   pack_frame         one wavefront per 32 blocks: [code][csize:3] headers, block payloads or raw copy,
+//   pack_frame         four wavefronts per superblock, destination-ordered gather of the block slots,
 //                      frame header (stenos.cpp:862-874)
 // Decode pipeline:
 //   walk_superblocks   (only without an index) serial walk of the [code][csize:3] chain (stenos.cpp:1129-1134)
@@ -29,10 +29,11 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 template <uint32_t TT>
 __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t nfull, uint32_t tail_bytes, uint32_t Trt,
 						    uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ bsize,
-						    uint32_t* __restrict__ binfo)
+						    uint32_t* __restrict__ binfo, uint32_t dbg)
 {
 	const uint32_t T = TT ? TT : Trt;
-	const Layout L = make_layout(T, true);
+	Layout L = make_layout(T, true);
+	L.dbg = dbg; // diagnostics only, 0 in normal operation
 	const uint64_t nblocks = nfull + (tail_bytes ? 1 : 0);
 	for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
 		BlockInfo r;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64) void resolve_frame(FrameJob j)
 	resolve_capacity(g_lds, L, j);
 }
 
-__global__ __launch_bounds__(64) void pack_frame(FrameJob j, uint32_t wps) { pack_blocks(j, blockIdx.x / wps, blockIdx.x % wps); }
+__global__ __launch_bounds__(64) void pack_frame(FrameJob j) { pack_superblock(g_lds, j, blockIdx.x / PACK_WAVES, blockIdx.x % PACK_WAVES); }
 
 // Serial walk of the superblock chain by one lane: off[s] = byte offset of superblock s's header.
 __global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* __restrict__ off,
@@ -206,7 +207,8 @@ static hipError_t launch_encode_t(const FrameJob& j, hipStream_t stream)
 		const uint64_t resident = (uint64_t)stenos_k_cu_count() * stenos_k_waves_per_cu(lds);
 		grid = (uint32_t)(nblocks < resident ? nblocks : resident);
 	}
-	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride, j.bsize, j.binfo);
+	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride, j.bsize, j.binfo,
+			   getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
 	return hipGetLastError();
 }
 
@@ -246,8 +248,7 @@ hipError_t stenos_k_launch_resolve(const FrameJob& j, hipStream_t stream)
 
 hipError_t stenos_k_launch_pack(const FrameJob& j, hipStream_t stream)
 {
-	const uint32_t wps = pack_waves_per_superblock(j.bps);
-	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)(j.nsb * wps)), dim3(64), 0, stream, j, wps);
+	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)(j.nsb * PACK_WAVES)), dim3(64), pack_lds_bytes(j.bps), stream, j);
 	return hipGetLastError();
 }
 

@@ -188,13 +188,28 @@ WV_FN void resolve_capacity(Lds lds, const Layout& L, const FrameJob& j)
 	gstore_uniform64(j.total, off);
 }
 
-// Blocks handed to one wavefront of the pack step: their offsets and sizes are fetched with one vector
-// load and the copies of consecutive blocks overlap in the memory system.
-constexpr uint32_t PACK_BLOCKS = 32;
-WV_HD uint32_t pack_waves_per_superblock(uint32_t bps) { return (bps + 1 + PACK_BLOCKS - 1) / PACK_BLOCKS; }
+// Pack step: PACK_WAVES wavefronts per superblock, each writing one contiguous quarter of the superblock's
+// bytes in the frame.  The work is laid out over the DESTINATION: every lane produces aligned destination
+// dwords (fully coalesced stores) and finds the block slot its bytes come from with a short forward scan
+// of the block-offset table held in the wave's LDS, so all loads of an iteration are independent.
+constexpr uint32_t PACK_WAVES = 4;
+WV_HD uint32_t pack_lds_bytes(uint32_t bps) { return align16((bps + 3) * 4) + 16; }
 
-// Wavefront `w` of superblock `s`: headers + payload of blocks [w*PACK_BLOCKS, ...) into the frame.
-WV_FN void pack_blocks(const FrameJob& j, uint64_t s, uint32_t w)
+// source byte p of the payload of a BLOCK superblock: block bi holds payload bytes [off[bi], off[bi+1])
+WV_FN U32 pack_src_byte(const FrameJob& j, Lds tab, uint64_t first, const U32& p, U32 bi, uint32_t count, const Pred& valid)
+{
+	// advance to the block that contains p (blocks are at least header_bytes + T bytes long)
+	for (;;) {
+		Pred adv = valid & (bi + 1u < U32(count)) & (p >= lds_ld32(tab, (bi + 1u) * 4u));
+		if (!any(adv))
+			break;
+		bi = sel(adv, bi + 1u, bi);
+	}
+	U32 rel = p - lds_ld32(tab, bi * 4u);
+	return gld8(j.slots + first * (uint64_t)j.slot_stride, bi * j.slot_stride + rel, valid);
+}
+
+WV_FN void pack_superblock(Lds lds, const FrameJob& j, uint64_t s, uint32_t w)
 {
 	const U32 lane = lane_id();
 	if (gload_uniform(j.status))
@@ -203,10 +218,6 @@ WV_FN void pack_blocks(const FrameJob& j, uint64_t s, uint32_t w)
 	if (total > j.dst_size) // never write past the caller's buffer; the host reports DST_OVERFLOW
 		return;
 	const uint32_t count = superblock_blocks(j, s);
-	const uint32_t k0 = w * PACK_BLOCKS;
-	if (k0 >= count)
-		return;
-	const uint32_t k1 = k0 + PACK_BLOCKS < count ? k0 + PACK_BLOCKS : count;
 	const uint64_t first = s * j.bps;
 	const bool has_tail = s == j.nsb - 1 && j.tail_bytes;
 	uint8_t* base = j.dst + gload_uniform64(j.sb_off + s);
@@ -221,22 +232,105 @@ WV_FN void pack_blocks(const FrameJob& j, uint64_t s, uint32_t w)
 	}
 	if (w == 0) // superblock header [code][csize:3 LE] (stenos.cpp:613-615)
 		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
-	if (j.tiny_last && s == j.nsb - 1) { // payload prepared by the host (zstd or raw bytes)
-		copy_g2g(base + 4, j.override_payload, csize);
+	uint8_t* pay = base + 4;
+	// this wave's share of the payload, cut at destination dword boundaries
+	const uint32_t mis = (uint32_t)((uintptr_t)pay & 3u);
+	const uint32_t ndw = (mis + csize + 3) >> 2;                  // aligned destination dwords touched by the payload
+	const uint32_t per = (ndw + PACK_WAVES - 1) / PACK_WAVES;
+	const uint32_t d0 = w * per < ndw ? w * per : ndw, d1 = d0 + per < ndw ? d0 + per : ndw;
+	if (d0 >= d1)
+		return;
+	if ((j.tiny_last && s == j.nsb - 1) || code != 1) {
+		// one contiguous source: the host-prepared payload, or the raw input bytes of a COPY superblock
+		const uint8_t* srcp = (j.tiny_last && s == j.nsb - 1) ? j.override_payload : j.src + first * (uint64_t)(256 * j.T);
+		const uint32_t b0 = d0 * 4 > mis ? d0 * 4 - mis : 0, b1 = d1 * 4 - mis < csize ? d1 * 4 - mis : csize;
+		copy_g2g(pay + b0, srcp + b0, b1 - b0);
 		return;
 	}
-	const uint32_t bs = 256 * j.T;
-	if (code != 1) { // copy superblock: the raw input bytes of these blocks in one piece
-		const uint64_t begin = (uint64_t)k0 * bs;
-		const uint64_t end = (has_tail && k1 == count) ? (uint64_t)(count - 1) * bs + j.tail_bytes : (uint64_t)k1 * bs;
-		copy_g2g(base + 4 + begin, j.src + first * (uint64_t)bs + begin, (uint32_t)(end - begin));
-		return;
+	(void)has_tail;
+	// block offsets of this superblock -> LDS (count + 1 entries, the last one is the payload size)
+	for (uint32_t o = 0; o < count; o += 64) {
+		Pred p = (U32(o) + lane) < U32(count);
+		lds_st32(lds, (U32(o) + lane) * 4u, gld32((const uint8_t*)(j.boff + first), (U32(o) + lane) * 4u, p), p);
 	}
-	Pred mine = (U32(k0) + lane) < U32(k1);
-	U32 offs = gld32((const uint8_t*)(j.boff + first + k0), lane * 4u, mine);
-	U32 sizes = gld32((const uint8_t*)(j.bsize + first + k0), lane * 4u, mine);
-	for (uint32_t k = k0; k < k1; ++k)
-		copy_g2g(base + 4 + readlane(offs, k - k0), j.slots + (first + k) * (uint64_t)j.slot_stride, readlane(sizes, k - k0));
+	lds_st32(lds, U32(count * 4u), U32(csize), lane == U32(0u));
+	wave_sync();
+	// Lanes own 16 consecutive destination bytes per iteration (one 16-byte store, five independent aligned
+	// loads).  Groups that lie inside one block take that path; groups cut by a block boundary or by the
+	// ends of the payload fall back to dwords, and dwords cut the same way to bytes.
+	const uint32_t mis16 = (uint32_t)((uintptr_t)pay & 15u);
+	uint8_t* abase = pay - mis16; // 16-byte aligned
+	const uint32_t b0 = d0 * 4 > mis ? d0 * 4 - mis : 0;                       // payload bytes [b0, b1) belong to this wave
+	const uint32_t b1 = d1 * 4 - mis < csize ? d1 * 4 - mis : csize;
+	const uint32_t g0 = (mis16 + b0) >> 4, g1 = (mis16 + b1 + 15) >> 4;        // 16-byte groups touched
+	uint32_t lo = 0;
+	for (uint32_t o = 0; o < count; o += 64) { // block that holds payload byte b0
+		Pred in = (U32(o) + lane) < U32(count);
+		uint64_t m = ballot(in & (lds_ld32(lds, (U32(o) + lane + 1u) * 4u) > U32(b0)));
+		if (m) {
+			lo = o + (uint32_t)__builtin_ctzll(m);
+			break;
+		}
+	}
+	const uint8_t* slot0 = j.slots + first * (uint64_t)j.slot_stride;
+	for (uint32_t g = g0; g < g1; g += 64) {
+		U32 gi = U32(g) + lane;
+		Pred act = gi < U32(g1);
+		// payload range of this group clipped to the wave's share: [q0, q1)
+		U32 gp = gi * 16u;                                       // offset from abase
+		U32 q0 = umax(gp, U32(mis16 + b0)) - U32(mis16);
+		U32 q1 = umin(gp + 16u, U32(mis16 + b1)) - U32(mis16);
+		Pred whole = act & (q1 - q0 == U32(16u));
+		U32 bi(lo);
+		for (;;) { // forward scan to the block of byte q0
+			Pred adv = act & (bi + 1u < U32(count)) & (q0 >= lds_ld32(lds, (bi + 1u) * 4u));
+			if (!any(adv))
+				break;
+			bi = sel(adv, bi + 1u, bi);
+		}
+		U32 bstart = lds_ld32(lds, bi * 4u), bend = lds_ld32(lds, (bi + 1u) * 4u);
+		Pred fast = whole & (q0 + 16u <= bend);
+		{
+			U32 soff = bi * j.slot_stride + (q0 - bstart);
+			U32 sa = soff & ~3u, sh = (soff & 3u) << 3;
+			U32 w0 = gld32(slot0, sa, fast), w1 = gld32(slot0, sa + 4u, fast), w2 = gld32(slot0, sa + 8u, fast), w3 = gld32(slot0, sa + 12u, fast);
+			U32 w4 = gld32(slot0, sa + 16u, fast & (sh != U32(0u)));
+			U32 ish = U32(32u) - sh;
+			U128 v;
+			v.x = sel(sh == U32(0u), w0, (w0 >> sh) | (w1 << ish));
+			v.y = sel(sh == U32(0u), w1, (w1 >> sh) | (w2 << ish));
+			v.z = sel(sh == U32(0u), w2, (w2 >> sh) | (w3 << ish));
+			v.w = sel(sh == U32(0u), w3, (w3 >> sh) | (w4 << ish));
+			gst128(abase, gp, v, fast);
+		}
+		Pred slow = act & !fast;
+		if (any(slow))
+			for (uint32_t k = 0; k < 4; ++k) { // dword k of the group
+				U32 dq = gp + U32(4 * k) - U32(mis16); // payload position of its first byte (may wrap below 0)
+				Pred din = slow & (gp + U32(4 * k) >= U32(mis16 + b0)) & (gp + U32(4 * k + 4) <= U32(mis16 + b1));
+				U32 bk = bi;
+				for (;;) {
+					Pred adv = din & (bk + 1u < U32(count)) & (dq >= lds_ld32(lds, (bk + 1u) * 4u));
+					if (!any(adv))
+						break;
+					bk = sel(adv, bk + 1u, bk);
+				}
+				Pred dfast = din & (dq + 4u <= lds_ld32(lds, (bk + 1u) * 4u));
+				U32 soff = bk * j.slot_stride + (dq - lds_ld32(lds, bk * 4u));
+				U32 sa = soff & ~3u, sh = (soff & 3u) << 3;
+				U32 w0 = gld32(slot0, sa, dfast), w1 = gld32(slot0, sa + 4u, dfast & (sh != U32(0u)));
+				gst32(abase, gp + U32(4 * k), sel(sh == U32(0u), w0, (w0 >> sh) | (w1 << (U32(32u) - sh))), dfast);
+				Pred dslow = slow & !dfast;
+				if (any(dslow))
+					for (uint32_t c = 0; c < 4; ++c) {
+						U32 ap = gp + U32(4 * k + c); // offset from abase
+						Pred ok = dslow & (ap >= U32(mis16 + b0)) & (ap < U32(mis16 + b1));
+						U32 byte = pack_src_byte(j, lds, first, sel(ok, ap - U32(mis16), U32(0u)), bi, count, ok);
+						gst8(abase, ap, byte, ok);
+					}
+			}
+		lo = readlane(bi, 0); // the next iteration starts at or after this lane's block
+	}
 }
 
 } // namespace codec

@@ -245,6 +245,19 @@ WV_FN U32 lds_add_rtn32(Lds m, const U32& a, const U32& v, const Pred& p)
 		}
 	return r;
 }
+// compare-and-swap returning the previous value
+WV_FN U32 lds_cas32(Lds m, const U32& a, const U32& expect, const U32& v, const Pred& p)
+{
+	U32 r(0u);
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			uint32_t t;
+			memcpy(&t, m + (a.l[i] & ~3u), 4);
+			r.l[i] = t;
+			if (t == expect.l[i]) memcpy(m + (a.l[i] & ~3u), &v.l[i], 4);
+		}
+	return r;
+}
 WV_FN void lds_or32(Lds m, const U32& a, const U32& v, const Pred& p)
 {
 	for (int i = 0; i < WAVE; ++i)
@@ -356,7 +369,12 @@ typedef uint8_t* Lds; // points into __shared__ memory
 
 WV_FN Pred pred_all(bool v) { return v; }
 WV_FN U32 sel(Pred p, U32 a, U32 b) { return p ? a : b; }
-WV_FN U32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+WV_FN U32 lane_id()
+{
+	U32 l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	__builtin_assume(l < 64u); // lets the compiler drop predicates that are always true for a full wave
+	return l;
+}
 WV_FN U32 umin(U32 a, U32 b) { return a < b ? a : b; }
 WV_FN U32 umax(U32 a, U32 b) { return a > b ? a : b; }
 WV_FN U32 popc(U32 a) { return (U32)__builtin_popcount(a); }
@@ -444,6 +462,12 @@ WV_FN void lds_st32(Lds m, U32 a, U32 v, Pred p)
 WV_FN void lds_st8(Lds m, U32 a, U32 v, Pred p)
 {
 	if (p) m[a] = (uint8_t)v;
+}
+WV_FN U32 lds_cas32(Lds m, U32 a, U32 expect, U32 v, Pred p)
+{
+	uint32_t e = expect;
+	if (p) __hip_atomic_compare_exchange_strong((uint32_t*)(m + (a & ~3u)), &e, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	return e; // the value found (== expect when the swap happened)
 }
 WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
 {

@@ -194,10 +194,11 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 		}
 	}
 	if (!result) {
-		const uint32_t wps = pack_waves_per_superblock(j.bps);
+		uint8_t* plds = alloc_lds(pack_lds_bytes(j.bps));
 		for (uint64_t s = 0; s < j.nsb; ++s) // pack_frame
-			for (uint32_t w = 0; w < wps; ++w)
-				pack_blocks(j, s, w);
+			for (uint32_t w = 0; w < PACK_WAVES; ++w)
+				pack_superblock(plds, j, s, w);
+		free(plds);
 		if (status || total > dst_size)
 			result = ERR_DST;
 		else {

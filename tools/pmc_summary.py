@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc (tools/pmc_run.sh) per kernel and write profiles/pmc_traffic.json.
+HBM bytes per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024: on gfx950 FETCH_SIZE reports half of a
+wide coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte stores."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for p in sorted(glob.glob(os.path.join(ROOT, "gpurun_out/pmc/p*/*/*_counter_collection.csv"))):
+    for r in csv.DictReader(open(p)):
+        k = r["Kernel_Name"]
+        if "anonymous namespace" not in k or "elementwise_kernel_with_index" in k or "at::native" in k:
+            continue
+        name = k.split("::")[1].split("(")[0].split("<")[0]
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for name, cs in agg.items():
+    out[name] = {c: sum(v) / len(v) for c, v in cs.items()}
+    out[name]["launches_averaged"] = len(next(iter(cs.values())))
+res = {"source": "rocprofv3 --pmc (tools/pmc_run.sh), bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-entropy", "kernels": out}
+for k in ("encode_blocks", "pack_frame", "decode_superblocks"):
+    if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
+        res[f"{k}_hbm_bytes_per_launch"] = int(2 * out[k]["FETCH_SIZE"] * 1024 + out[k]["WRITE_SIZE"] * 1024)
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json"), "w") as f:
+    json.dump(res, f, indent=1)
+with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+    json.dump({k: v for k, v in res.items() if k.endswith("per_launch") or k == "source"}, f, indent=1)
+for name, cs in out.items():
+    w = cs.get("SQ_WAVES", 0)
+    line = f"{name:20s}"
+    if w:
+        line += f" waves {w:.0f} valu/wave {cs.get('SQ_INSTS_VALU',0)/w:.0f} salu/wave {cs.get('SQ_INSTS_SALU',0)/w:.0f}"
+        wc = cs.get("SQ_WAVE_CYCLES", 1)
+        line += f" active {cs.get('SQ_ACTIVE_INST_ANY',0)/wc:.2f} wait_inst {cs.get('SQ_WAIT_INST_ANY',0)/wc:.2f} wait_any {cs.get('SQ_WAIT_ANY',0)/wc:.2f}"
+    if "SQ_INSTS_LDS" in cs and w:
+        line += f" lds/wave {cs['SQ_INSTS_LDS']/w:.0f} bank_conflict/idx_active {cs.get('SQ_LDS_BANK_CONFLICT',0)/max(cs.get('SQ_LDS_IDX_ACTIVE',1),1):.2f}"
+    if "FETCH_SIZE" in cs:
+        line += f" fetchKB {cs['FETCH_SIZE']:.0f} writeKB {cs.get('WRITE_SIZE',0):.0f}"
+    print(line)
