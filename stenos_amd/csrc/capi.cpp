@@ -123,7 +123,7 @@ struct stenos_context_s {
 	bool probed = false, usable = false;
 	DevBuf in, out;                                  // staging for the host-pointer ABI
 	DevBuf slots, bsize, binfo, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
-	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [64,320) override payload
+	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [24,32) scan carry, [64,320) override payload
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
 	hipStream_t job_stream = nullptr;
@@ -135,6 +135,17 @@ struct stenos_context_s {
 	bool profiling = false;
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; // encode start/stop, decode start/stop
 	bool ev_valid[2] = { false, false };
+	// second stream and events for overlapping the pack of one chunk with the encoding of the next
+	hipStream_t aux_stream = nullptr;
+	hipEvent_t ev_chunk = nullptr, ev_join = nullptr;
+	bool ensure_aux()
+	{
+		if (aux_stream)
+			return true;
+		return hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) == hipSuccess &&
+		       hipEventCreateWithFlags(&ev_chunk, hipEventDisableTiming) == hipSuccess &&
+		       hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess;
+	}
 
 	bool device_ready()
 	{
@@ -157,6 +168,12 @@ struct stenos_context_s {
 		for (hipEvent_t e : ev)
 			if (e)
 				(void)hipEventDestroy(e);
+		if (ev_chunk)
+			(void)hipEventDestroy(ev_chunk);
+		if (ev_join)
+			(void)hipEventDestroy(ev_join);
+		if (aux_stream)
+			(void)hipStreamDestroy(aux_stream);
 	}
 	void mark(int idx, hipStream_t stream)
 	{
@@ -273,16 +290,75 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	j.tiny_last = tiny_last ? 1u : 0u;
 	j.override_code = 0;
 
+	j.check_total = 0;
+	const uint64_t header = j.header_bytes;
+
+	// Superblocks whose capacity is certainly large enough for any encoding ("safe zone", normally all but the
+	// last one or two) need no capacity replay and no overflow check; they are processed in chunks, the
+	// pack of a chunk overlapping the encoding of the next one on a second stream.  The remaining tail zone
+	// goes through plan / scan / resolve / pack in order.
+	const uint64_t need_max = (uint64_t)(f.bps + 1) * (256 * T + (T + 1) / 2) + 288 * T + 64;
+	const uint64_t fixed = header + 4 + need_max;
+	uint64_t s_tight = dst_size >= fixed ? (dst_size - fixed) / (f.sb + 4) + 1 : 0;
+	if (s_tight > f.nsb)
+		s_tight = f.nsb;
+	if (tiny_last && s_tight > f.nsb - 1)
+		s_tight = f.nsb - 1;
+	const uint64_t nblocks_all = f.nfull + (f.tail ? 1 : 0);
+	auto first_block = [&](uint64_t sb_index) { // first block of a superblock (nblocks_all for sb_index == nsb)
+		const uint64_t b = sb_index * f.bps;
+		return sb_index >= f.nsb ? nblocks_all : (b < f.nfull ? b : f.nfull);
+	};
+
+	uint64_t* d_carry = (uint64_t*)(misc + 24);
 	const uint32_t init[2] = { 0u, 0xFFFFFFFFu }; // status, first_flagged
-	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess)
+	const uint64_t carry0 = header;
+	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	    hipMemcpyAsync(d_carry, &carry0, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	    hipMemcpyAsync(j.total, &carry0, 8, hipMemcpyHostToDevice, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	ctx->mark(0, stream);
-	if (level >= 1 && stenos_k_launch_encode(j, stream) != hipSuccess)
-		return STENOS_ERROR_UNDEFINED;
-	ctx->mark(1, stream);
-	if (stenos_k_launch_plan(j, stream) != hipSuccess || stenos_k_launch_scan(j, stream) != hipSuccess ||
-	    stenos_k_launch_resolve(j, stream) != hipSuccess)
-		return STENOS_ERROR_UNDEFINED;
+	if (s_tight > 0) {
+		// Measured on MI355X (8 GiB int32): overlapping the pack of chunk k with the encoding of chunk k+1 on a
+		// second stream gains nothing (748-802 GB/s against 725-764 GB/s for one chunk; chunks below 128 MiB are
+		// launch-bound), so by default the safe zone is one chunk.  STENOS_CHUNK_MIB enables the chunked form.
+		uint64_t csb = s_tight;
+		if (const char* e = getenv("STENOS_CHUNK_MIB"))
+			if (atoi(e) > 0)
+				csb = ((uint64_t)atoi(e) << 20) / f.sb;
+		if (csb == 0)
+			csb = 1;
+		const bool overlap = s_tight > csb && ctx->ensure_aux();
+		hipStream_t s2 = overlap ? ctx->aux_stream : stream;
+		for (uint64_t s0 = 0; s0 < s_tight; s0 += csb) {
+			const uint64_t s1 = s0 + csb < s_tight ? s0 + csb : s_tight;
+			if (s0 == 0)
+				ctx->mark(0, stream); // kernel timing: the first (normally only) encode_blocks launch of the safe zone
+			if (level >= 1 && stenos_k_launch_encode(j, first_block(s0), first_block(s1), stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			if (s0 == 0)
+				ctx->mark(1, stream);
+			if (overlap && (hipEventRecord(ctx->ev_chunk, stream) != hipSuccess || hipStreamWaitEvent(s2, ctx->ev_chunk, 0) != hipSuccess))
+				return STENOS_ERROR_UNDEFINED;
+			if (stenos_k_launch_plan(j, s0, s1, s2) != hipSuccess || stenos_k_launch_scan(j, s0, s1, d_carry, s2) != hipSuccess ||
+			    stenos_k_launch_pack(j, s0, s1, s2) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+		}
+		if (overlap && (hipEventRecord(ctx->ev_join, s2) != hipSuccess || hipStreamWaitEvent(stream, ctx->ev_join, 0) != hipSuccess))
+			return STENOS_ERROR_UNDEFINED;
+	}
+	// tail zone
+	j.check_total = 1;
+	if (s_tight < f.nsb) {
+		if (s_tight == 0)
+			ctx->mark(0, stream);
+		if (level >= 1 && stenos_k_launch_encode(j, first_block(s_tight), nblocks_all, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		if (s_tight == 0)
+			ctx->mark(1, stream);
+		if (stenos_k_launch_plan(j, s_tight, f.nsb, stream) != hipSuccess || stenos_k_launch_scan(j, s_tight, f.nsb, d_carry, stream) != hipSuccess ||
+		    stenos_k_launch_resolve(j, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+	}
 
 	if (tiny_last) {
 		// The reference hands zstd the rest of the caller's buffer as capacity (stenos.cpp:666, 895), and
@@ -320,7 +396,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 			return STENOS_ERROR_UNDEFINED;
 		j.override_code = code;
 	}
-	if (stenos_k_launch_pack(j, stream) != hipSuccess)
+	if (stenos_k_launch_pack(j, s_tight, f.nsb, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	// total (8 bytes) and the encode status (4 bytes at +12) travel together
 	if (hipMemcpyAsync(ctx->h_total, misc, 16, hipMemcpyDeviceToHost, stream) != hipSuccess)

@@ -30,10 +30,10 @@ size_t stenos_k_encode_lds_bytes(uint32_t T);
 size_t stenos_k_decode_lds_bytes(uint32_t T);
 uint32_t stenos_k_slot_stride(uint32_t T);
 
-hipError_t stenos_k_launch_encode(const codec::FrameJob& j, hipStream_t stream);
-hipError_t stenos_k_launch_plan(const codec::FrameJob& j, hipStream_t stream);
-hipError_t stenos_k_launch_scan(const codec::FrameJob& j, hipStream_t stream);
+hipError_t stenos_k_launch_encode(const codec::FrameJob& j, uint64_t b_begin, uint64_t b_end, hipStream_t stream);
+hipError_t stenos_k_launch_plan(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
+hipError_t stenos_k_launch_scan(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, uint64_t* carry, hipStream_t stream);
 hipError_t stenos_k_launch_resolve(const codec::FrameJob& j, hipStream_t stream);
-hipError_t stenos_k_launch_pack(const codec::FrameJob& j, hipStream_t stream);
+hipError_t stenos_k_launch_pack(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
 hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream);
 hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream);

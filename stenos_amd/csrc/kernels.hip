@@ -27,15 +27,14 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 
 // TT: bytesoftype known at compile time (2, 4, 8: loops unroll, plane words stay in registers) or 0 = runtime value
 template <uint32_t TT>
-__global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t nfull, uint32_t tail_bytes, uint32_t Trt,
+__global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t b_begin, uint64_t b_end, uint64_t nfull, uint32_t tail_bytes, uint32_t Trt,
 						    uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ bsize,
 						    uint32_t* __restrict__ binfo, uint32_t dbg)
 {
 	const uint32_t T = TT ? TT : Trt;
 	Layout L = make_layout(T, true);
 	L.dbg = dbg; // diagnostics only, 0 in normal operation
-	const uint64_t nblocks = nfull + (tail_bytes ? 1 : 0);
-	for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+	for (uint64_t b = b_begin + blockIdx.x; b < b_end; b += gridDim.x) {
 		BlockInfo r;
 		if (b < nfull)
 			r = encode_block_job(g_lds, L, T, src + b * (uint64_t)(256 * T), slots + b * (uint64_t)slot_stride, true);
@@ -49,19 +48,22 @@ __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ 
 }
 
 // One wavefront per superblock.
-__global__ __launch_bounds__(64) void plan_superblocks(FrameJob j) { plan_superblock(j, blockIdx.x); }
+__global__ __launch_bounds__(64) void plan_superblocks(FrameJob j, uint64_t s_begin) { plan_superblock(j, s_begin + blockIdx.x); }
 
-// Exclusive scan of (csize + 4) over the superblocks by one workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restrict__ csize, uint64_t nsb, uint64_t header_bytes,
+// Exclusive scan of (csize + 4) over superblocks [s_begin, s_begin + n) by one workgroup of 1024 threads.
+// *carry holds the frame offset of superblock s_begin on entry and of s_begin + n on exit, so consecutive
+// ranges chain on the device.
+__global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restrict__ csize, uint64_t s_begin, uint64_t n, uint64_t* __restrict__ carry,
 							 uint64_t* __restrict__ off, uint64_t* __restrict__ total)
 {
 	__shared__ uint64_t partial[1024];
 	const uint32_t tid = threadIdx.x;
-	const uint64_t per = (nsb + 1023) / 1024;
-	const uint64_t lo = tid * per < nsb ? tid * per : nsb, hi = lo + per < nsb ? lo + per : nsb;
+	const uint64_t per = (n + 1023) / 1024;
+	const uint64_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+	const uint64_t start = *carry;
 	uint64_t sum = 0;
 	for (uint64_t i = lo; i < hi; ++i)
-		sum += (uint64_t)csize[i] + 4;
+		sum += (uint64_t)csize[s_begin + i] + 4;
 	partial[tid] = sum;
 	__syncthreads();
 	for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
@@ -70,14 +72,16 @@ __global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restr
 		partial[tid] += v;
 		__syncthreads();
 	}
-	uint64_t base = header_bytes + partial[tid] - sum;
+	uint64_t base = start + partial[tid] - sum;
 	for (uint64_t i = lo; i < hi; ++i) {
-		off[i] = base;
-		base += (uint64_t)csize[i] + 4;
+		off[s_begin + i] = base;
+		base += (uint64_t)csize[s_begin + i] + 4;
 	}
+	__syncthreads(); // every thread has read *carry
 	if (tid == 1023) {
-		off[nsb] = header_bytes + partial[1023];
-		*total = header_bytes + partial[1023];
+		off[s_begin + n] = start + partial[1023];
+		*total = start + partial[1023];
+		*carry = start + partial[1023];
 	}
 }
 
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(64) void resolve_frame(FrameJob j)
 	resolve_capacity(g_lds, L, j);
 }
 
-__global__ __launch_bounds__(64) void pack_frame(FrameJob j) { pack_superblock(g_lds, j, blockIdx.x / PACK_WAVES, blockIdx.x % PACK_WAVES); }
+__global__ __launch_bounds__(64) void pack_frame(FrameJob j, uint64_t s_begin) { pack_superblock(g_lds, j, s_begin + blockIdx.x / PACK_WAVES, blockIdx.x % PACK_WAVES); }
 
 // Serial walk of the superblock chain by one lane: off[s] = byte offset of superblock s's header.
 __global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* __restrict__ off,
@@ -192,47 +196,55 @@ size_t stenos_k_decode_lds_bytes(uint32_t T) { return make_dec_layout(T).total; 
 uint32_t stenos_k_slot_stride(uint32_t T) { return out_capacity(T); }
 
 template <uint32_t TT>
-static hipError_t launch_encode_t(const FrameJob& j, hipStream_t stream)
+static hipError_t launch_encode_t(const FrameJob& j, uint64_t b_begin, uint64_t b_end, hipStream_t stream)
 {
-	const uint64_t nblocks = j.nfull + (j.tail_bytes ? 1 : 0);
-	const size_t lds = stenos_k_encode_lds_bytes(j.T);
+	size_t lds = stenos_k_encode_lds_bytes(j.T);
+	if (getenv("STENOS_EXP_SMALL_LDS"))
+		lds = (size_t)atoi(getenv("STENOS_EXP_SMALL_LDS"));
 	hipError_t e = hipFuncSetAttribute((const void*)encode_blocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
 	// One workgroup per block measured faster than a persistent grid on MI355X (10.4 ms vs 12.5-14.8 ms for
 	// 8 GiB of int32): the dispatcher staggers the waves, a resident grid runs them in phase.  The
 	// grid-stride form stays available for experiments through STENOS_WAVES_PER_CU.
+	const uint64_t nblocks = b_end - b_begin;
 	uint32_t grid = (uint32_t)nblocks;
 	if (getenv("STENOS_WAVES_PER_CU")) {
 		const uint64_t resident = (uint64_t)stenos_k_cu_count() * stenos_k_waves_per_cu(lds);
 		grid = (uint32_t)(nblocks < resident ? nblocks : resident);
 	}
-	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride, j.bsize, j.binfo,
-			   getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
+	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, b_begin, b_end, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride,
+			   j.bsize, j.binfo, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
 	return hipGetLastError();
 }
 
-hipError_t stenos_k_launch_encode(const FrameJob& j, hipStream_t stream)
+// blocks [b_begin, b_end) of the job (the tail block has index nfull)
+hipError_t stenos_k_launch_encode(const FrameJob& j, uint64_t b_begin, uint64_t b_end, hipStream_t stream)
 {
-	if (j.nfull + (j.tail_bytes ? 1 : 0) == 0)
+	if (b_end <= b_begin)
 		return hipSuccess;
 	switch (j.T) {
-		case 2: return launch_encode_t<2>(j, stream);
-		case 4: return launch_encode_t<4>(j, stream);
-		case 8: return launch_encode_t<8>(j, stream);
-		default: return launch_encode_t<0>(j, stream);
+		case 2: return launch_encode_t<2>(j, b_begin, b_end, stream);
+		case 4: return launch_encode_t<4>(j, b_begin, b_end, stream);
+		case 8: return launch_encode_t<8>(j, b_begin, b_end, stream);
+		default: return launch_encode_t<0>(j, b_begin, b_end, stream);
 	}
 }
 
-hipError_t stenos_k_launch_plan(const FrameJob& j, hipStream_t stream)
+// superblocks [s_begin, s_end)
+hipError_t stenos_k_launch_plan(const FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream)
 {
-	hipLaunchKernelGGL(plan_superblocks, dim3((uint32_t)j.nsb), dim3(64), 0, stream, j);
+	if (s_end <= s_begin)
+		return hipSuccess;
+	hipLaunchKernelGGL(plan_superblocks, dim3((uint32_t)(s_end - s_begin)), dim3(64), 0, stream, j, s_begin);
 	return hipGetLastError();
 }
 
-hipError_t stenos_k_launch_scan(const FrameJob& j, hipStream_t stream)
+hipError_t stenos_k_launch_scan(const FrameJob& j, uint64_t s_begin, uint64_t s_end, uint64_t* carry, hipStream_t stream)
 {
-	hipLaunchKernelGGL(scan_superblocks, dim3(1), dim3(1024), 0, stream, j.sb_csize, j.nsb, (uint64_t)j.header_bytes, j.sb_off, j.total);
+	if (s_end <= s_begin)
+		return hipSuccess;
+	hipLaunchKernelGGL(scan_superblocks, dim3(1), dim3(1024), 0, stream, j.sb_csize, s_begin, s_end - s_begin, carry, j.sb_off, j.total);
 	return hipGetLastError();
 }
 
@@ -246,9 +258,11 @@ hipError_t stenos_k_launch_resolve(const FrameJob& j, hipStream_t stream)
 	return hipGetLastError();
 }
 
-hipError_t stenos_k_launch_pack(const FrameJob& j, hipStream_t stream)
+hipError_t stenos_k_launch_pack(const FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream)
 {
-	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)(j.nsb * PACK_WAVES)), dim3(64), pack_lds_bytes(j.bps), stream, j);
+	if (s_end <= s_begin)
+		return hipSuccess;
+	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)((s_end - s_begin) * PACK_WAVES)), dim3(64), pack_lds_bytes(j.bps), stream, j, s_begin);
 	return hipGetLastError();
 }
 

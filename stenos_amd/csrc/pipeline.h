@@ -49,6 +49,7 @@ struct FrameJob {
 	uint32_t force_copy;   // level 0
 	uint32_t tiny_last;    // the last superblock is shorter than 128 bytes: finished by the host (zstd)
 	uint32_t override_code; // set by the host for the tiny last superblock before pack
+	uint32_t check_total;   // pack: compare *total with dst_size first (not needed where the plan proved that everything fits)
 };
 
 WV_HD uint32_t superblock_bytes(const FrameJob& j, uint64_t s)
@@ -214,8 +215,7 @@ WV_FN void pack_superblock(Lds lds, const FrameJob& j, uint64_t s, uint32_t w)
 	const U32 lane = lane_id();
 	if (gload_uniform(j.status))
 		return;
-	const uint64_t total = gload_uniform64(j.total);
-	if (total > j.dst_size) // never write past the caller's buffer; the host reports DST_OVERFLOW
+	if (j.check_total && gload_uniform64(j.total) > j.dst_size) // never write past the caller's buffer; the host reports DST_OVERFLOW
 		return;
 	const uint32_t count = superblock_blocks(j, s);
 	const uint64_t first = s * j.bps;

@@ -138,6 +138,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	j.status = &status;
 	j.first_flagged = &first_flagged;
 	j.override_payload = payload.data();
+	j.check_total = 1;
 	Layout L = make_layout((uint32_t)T, true);
 	uint8_t* lds = alloc_lds(L.total);
 	if (level >= 1)
