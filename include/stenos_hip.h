@@ -42,6 +42,15 @@ STENOS_EXPORT const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t*
 STENOS_EXPORT size_t stenos_hip_decompress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
 STENOS_EXPORT size_t stenos_hip_decompress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
 
+/* Whole-buffer byte kernels of the path on device memory (reference stenos/internal/shuffle.h:33,45 and
+ * delta.h:34,39): byte transpose of `bytes / bytesoftype` elements and its inverse (leftover bytes copied),
+ * byte delta in four quarter streams above 2048 bytes and its inverse.  src and dst must not overlap.
+ * Return 0 or an error code. */
+STENOS_EXPORT size_t stenos_hip_shuffle(const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, void* stream);
+STENOS_EXPORT size_t stenos_hip_unshuffle(const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, void* stream);
+STENOS_EXPORT size_t stenos_hip_delta(const void* d_src, void* d_dst, size_t bytes, void* stream);
+STENOS_EXPORT size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t bytes, void* stream);
+
 /* Kernel timing for benchmarks: when enabled, HIP events are recorded on the job's stream around the
  * dominant kernel of each direction (encode_blocks, decode_superblocks).  stenos_hip_kernel_ms returns the
  * elapsed milliseconds of the last such launch (which: 0 = encode_blocks, 1 = decode_superblocks), or a

@@ -1026,7 +1026,7 @@ size_t so_compress(const void* _src, size_t T, size_t bytes, void* _dst, size_t 
 }
 
 /* stenos_decompress -> stenos_decompress_generic serial path, stenos.cpp:1052-1149, and
- * decompress_generic_superblock, stenos.cpp:681-753 (codes 1, 2, 6) */
+ * decompress_generic_superblock, stenos.cpp:681-753 (all codes; zstd through dlopen) */
 size_t so_decompress(const void* _src, size_t T, size_t size, void* _dst, size_t dst_size, int fix_exact_multiple)
 {
 	const uint8_t* s = (const uint8_t*)_src;
@@ -1085,13 +1085,43 @@ size_t so_decompress(const void* _src, size_t T, size_t size, void* _dst, size_t
 				if (z_iserror(r))
 					return SO_ERROR_INVALID_INPUT;
 			} break;
+			case 3: /* zstd on the transposed superblock, stenos.cpp:700-710 */
+			case 4: /* zstd on transposed + byte delta, stenos.cpp:711-725 */
+			case 5: { /* zstd over the block stream, stenos.cpp:726-740 */
+				if (!load_zstd())
+					return SO_ERROR_ZSTD_INTERNAL;
+				size_t cap = code == 5 ? sb + 64 : dsize;
+				uint8_t* t1 = (uint8_t*)malloc(cap + 1);
+				uint8_t* t2 = (uint8_t*)malloc(cap + 1);
+				if (!t1 || !t2) {
+					free(t1);
+					free(t2);
+					return SO_ERROR_ALLOC;
+				}
+				size_t r = z_decompress(t1, cap, s, csize);
+				size_t err = 0;
+				if (z_iserror(r) || (code != 5 && r != dsize))
+					err = SO_ERROR_INVALID_INPUT;
+				else if (code == 3)
+					so_unshuffle(T, dsize, t1, dst + done);
+				else if (code == 4) {
+					so_delta_inv(t1, t2, dsize);
+					so_unshuffle(T, dsize, t2, dst + done);
+				}
+				else if (so_has_error(so_block_decompress(t1, r, T, dsize, dst + done)))
+					err = SO_ERROR_INVALID_INPUT;
+				free(t1);
+				free(t2);
+				if (err)
+					return err;
+			} break;
 			case 6:
 				if (dsize != csize)
 					return SO_ERROR_INVALID_INPUT;
 				memcpy(dst + done, s, csize);
 				break;
 			default:
-				return SO_ERROR_INVALID_INPUT; /* codes 3-5 are outside the oracle's scope */
+				return SO_ERROR_INVALID_INPUT;
 		}
 		done += dsize;
 		s += csize;

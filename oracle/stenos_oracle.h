@@ -13,7 +13,9 @@
  * from that build (tests/golden/make_golden.py).
  *
  * Scope: levels 0 and 1 for bytesoftype > 1 (superblock codes 1 BLOCK, 6 COPY, and code 2 ZSTD
- * for superblocks shorter than 128 bytes through a dlopen'ed libzstd), the whole block decoder.
+ * for superblocks shorter than 128 bytes through a dlopen'ed libzstd), the whole block decoder, and
+ * DECODING of every superblock code (2-5 through libzstd + unshuffle / delta_inv / block decoder), so that
+ * frames the reference produced at levels >= 2 can be checked.
  * Mini-LZ hash table starts empty for every block (see DESIGN.md "LZ table determinism").
  */
 #ifndef STENOS_ORACLE_H

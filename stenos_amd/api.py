@@ -74,6 +74,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "stenos_hip_last_index": (vp, [vp, ctypes.POINTER(sz)]),
         "stenos_hip_decompress": (sz, [vp, vp, sz, sz, vp, sz, vp, vp]),
         "stenos_hip_decompress_async": (sz, [vp, vp, sz, sz, vp, sz, vp, vp]),
+        "stenos_hip_shuffle": (sz, [vp, sz, sz, vp, vp]),
+        "stenos_hip_unshuffle": (sz, [vp, sz, sz, vp, vp]),
+        "stenos_hip_delta": (sz, [vp, vp, sz, vp]),
+        "stenos_hip_delta_inv": (sz, [vp, vp, sz, vp]),
         "stenos_hip_set_profiling": (None, [vp, c_int]),
         "stenos_hip_kernel_ms": (ctypes.c_double, [vp, c_int]),
     }

@@ -123,6 +123,7 @@ struct stenos_context_s {
 	bool probed = false, usable = false;
 	DevBuf in, out;                                  // staging for the host-pointer ABI
 	DevBuf slots, bsize, binfo, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
+	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [24,32) scan carry, [64,320) override payload
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
@@ -160,7 +161,7 @@ struct stenos_context_s {
 	}
 	~stenos_context_s()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2 };
 		for (DevBuf* b : all)
 			b->release();
 		if (h_total)
@@ -481,20 +482,26 @@ size_t parse_frame(const uint8_t* h, size_t have, size_t T, size_t dst_size, Fra
 	return 0;
 }
 
-// Finish superblocks that carry zstd-only payloads (code 2) on the host; codes 3-5 are not handled yet.
-// h_index: nsb + 1 header offsets on the host; frame/dst are device pointers.
-size_t finish_host_codes(const uint8_t* d_frame, size_t size, const uint64_t* h_index, const FrameInfo& fi, uint8_t* d_dst, hipStream_t stream)
+// Finish the superblocks whose payload went through zstd (codes 2-5, decompress_generic_superblock,
+// stenos.cpp:694-740): zstd itself runs on the host (third-party entropy coder, dlopen'ed), the byte kernels and
+// the block decoder that follow it run on the device.  h_index: nsb + 1 header offsets on the host; h_frame: host
+// copy of the frame or NULL (then the headers and payloads are fetched from the device).
+size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const uint8_t* h_frame, size_t size, size_t T, const uint64_t* h_index,
+			 const FrameInfo& fi, uint8_t* d_dst, hipStream_t stream)
 {
 	std::vector<uint8_t> comp, raw;
 	for (uint64_t s = 0; s < fi.nsb; ++s) {
 		uint8_t hd[4];
 		if (h_index[s] + 4 > size)
 			return STENOS_ERROR_SRC_OVERFLOW;
-		if (hipMemcpyAsync(hd, d_frame + h_index[s], 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+		if (h_frame)
+			memcpy(hd, h_frame + h_index[s], 4);
+		else if (hipMemcpyAsync(hd, d_frame + h_index[s], 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
-		if (hd[0] == 1 || hd[0] == 6)
+		const unsigned code = hd[0];
+		if (code == 1 || code == 6)
 			continue;
-		if (hd[0] != 2)
+		if (code < 2 || code > 5)
 			return STENOS_ERROR_INVALID_INPUT;
 		if (!zstd().ok)
 			return STENOS_ERROR_ZSTD_INTERNAL;
@@ -503,22 +510,78 @@ size_t finish_host_codes(const uint8_t* d_frame, size_t size, const uint64_t* h_
 		const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
 		if (h_index[s] + 4 + csize > size)
 			return STENOS_ERROR_INVALID_INPUT;
-		comp.resize(csize);
-		raw.resize(dsize);
-		if (hipMemcpyAsync(comp.data(), d_frame + h_index[s] + 4, csize, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-		    hipStreamSynchronize(stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		size_t r = zstd().decompress(raw.data(), dsize, comp.data(), csize);
-		if (zstd().is_error(r)) // stenos.cpp:696-698
+		const uint8_t* payload = nullptr;
+		if (h_frame)
+			payload = h_frame + h_index[s] + 4;
+		else {
+			comp.resize(csize);
+			if (hipMemcpyAsync(comp.data(), d_frame + h_index[s] + 4, csize, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			    hipStreamSynchronize(stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			payload = comp.data();
+		}
+		const size_t cap = code == 5 ? fi.sb + 64 : dsize; // code 5: zstd over the block stream, at most the superblock size (stenos.cpp:732)
+		raw.resize(cap);
+		size_t r = zstd().decompress(raw.data(), cap, payload, csize);
+		if (zstd().is_error(r) || (code != 5 && code != 2 && r != dsize)) // stenos.cpp:696-698, 706-708, 718-720
 			return STENOS_ERROR_INVALID_INPUT;
-		if (hipMemcpyAsync(d_dst + begin, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+		if (code == 2) { // plain zstd
+			if (hipMemcpyAsync(d_dst + begin, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			continue;
+		}
+		if (!ctx->tmp1.ensure(cap + 64) || !ctx->tmp2.ensure(cap + 64))
+			return STENOS_ERROR_ALLOC;
+		uint8_t* t1 = ctx->tmp1.as<uint8_t>();
+		uint8_t* t2 = ctx->tmp2.as<uint8_t>();
+		if (code == 3) { // zstd on the transposed superblock (stenos.cpp:700-710)
+			if (hipMemcpyAsync(t1, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    stenos_k_launch_shuffle(t1, d_dst + begin, (uint32_t)T, dsize, true, stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+		}
+		else if (code == 4) { // transposed + byte delta (stenos.cpp:711-725)
+			if (hipMemcpyAsync(t1, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    stenos_k_launch_delta(t1, t2, dsize, true, stream) != hipSuccess ||
+			    stenos_k_launch_shuffle(t2, d_dst + begin, (uint32_t)T, dsize, true, stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+		}
+		else { // code 5: zstd over the block stream (stenos.cpp:726-740) -> one BLOCK superblock for the block decoder
+			if (T > kMaxT)
+				return STENOS_ERROR_INVALID_PARAMETER;
+			uint8_t h4[4] = { 1, (uint8_t)r, (uint8_t)(r >> 8), (uint8_t)(r >> 16) };
+			const uint64_t idx[2] = { 0, 4 + (uint64_t)r };
+			uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
+			uint64_t* d_idx = (uint64_t*)(ctx->misc.as<uint8_t>() + 32);
+			if (hipMemcpyAsync(t1, h4, 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    hipMemcpyAsync(t1 + 4, raw.data(), r, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    hipMemcpyAsync(d_idx, idx, 16, hipMemcpyHostToDevice, stream) != hipSuccess || hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			DecodeArgs a;
+			a.frame = t1;
+			a.size = 4 + r;
+			a.sb_off = d_idx;
+			a.dst = d_dst + begin;
+			a.total_bytes = dsize;
+			a.nsb = 1;
+			a.sb_bytes = (uint32_t)dsize;
+			a.T = (uint32_t)T;
+			a.status = d_status;
+			uint32_t status = 0;
+			if (stenos_k_launch_decode(a, stream) != hipSuccess || hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			    hipStreamSynchronize(stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			if (status)
+				return STENOS_ERROR_INVALID_INPUT;
+			continue;
+		}
+		if (hipStreamSynchronize(stream) != hipSuccess) // raw is reused by the next superblock
 			return STENOS_ERROR_UNDEFINED;
 	}
 	return 0;
 }
 
 size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_t size, void* d_dst, size_t dst_size, const uint64_t* d_index,
-			 const uint64_t* h_index, hipStream_t stream, bool wait)
+			 const uint64_t* h_index, const uint8_t* h_frame, hipStream_t stream, bool wait)
 {
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
@@ -575,7 +638,7 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 				return STENOS_ERROR_UNDEFINED;
 			h_index = idx.data();
 		}
-		e = finish_host_codes((const uint8_t*)d_src, size, h_index, fi, (uint8_t*)d_dst, stream);
+		e = finish_host_codes(ctx, (const uint8_t*)d_src, h_frame, size, T, h_index, fi, (uint8_t*)d_dst, stream);
 		return is_err(e) ? e : (size_t)fi.total;
 	}
 	return r;
@@ -718,7 +781,10 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	}
 	index[fi.nsb] = p;
 	uint8_t* out = (uint8_t*)dst;
-	if (!gpu_codes) { // copies and zstd-only superblocks: nothing for the GPU to do
+	bool device_codes = gpu_codes;
+	for (uint64_t s = 0; s < fi.nsb && !device_codes; ++s)
+		device_codes = in[index[s]] >= 3 && in[index[s]] <= 5;
+	if (!device_codes) { // copies and zstd-only superblocks: nothing for the GPU to do
 		for (uint64_t s = 0; s < fi.nsb; ++s) {
 			const uint64_t begin = s * (uint64_t)fi.sb;
 			const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
@@ -749,7 +815,7 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	    hipMemcpy(ctx->sboff.p, index.data(), (fi.nsb + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	(void)host_codes;
-	size_t r = decompress_device(ctx, ctx->in.p, bytesoftype, size, ctx->out.p, (size_t)fi.total, ctx->sboff.as<uint64_t>(), index.data(), nullptr, true);
+	size_t r = decompress_device(ctx, ctx->in.p, bytesoftype, size, ctx->out.p, (size_t)fi.total, ctx->sboff.as<uint64_t>(), index.data(), in, nullptr, true);
 	if (is_err(r))
 		return r;
 	if (hipMemcpy(dst, ctx->out.p, (size_t)fi.total, hipMemcpyDeviceToHost) != hipSuccess)
@@ -1010,6 +1076,28 @@ size_t finish_job(stenos_context_s* ctx)
 
 extern "C" {
 
+static size_t byte_kernel(hipError_t e) { return e == hipSuccess ? 0 : STENOS_ERROR_UNDEFINED; }
+size_t stenos_hip_shuffle(const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, void* stream)
+{
+	if (bytesoftype == 0 || bytesoftype >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	return byte_kernel(stenos_k_launch_shuffle((const uint8_t*)d_src, (uint8_t*)d_dst, (uint32_t)bytesoftype, bytes, false, (hipStream_t)stream));
+}
+size_t stenos_hip_unshuffle(const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, void* stream)
+{
+	if (bytesoftype == 0 || bytesoftype >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	return byte_kernel(stenos_k_launch_shuffle((const uint8_t*)d_src, (uint8_t*)d_dst, (uint32_t)bytesoftype, bytes, true, (hipStream_t)stream));
+}
+size_t stenos_hip_delta(const void* d_src, void* d_dst, size_t bytes, void* stream)
+{
+	return byte_kernel(stenos_k_launch_delta((const uint8_t*)d_src, (uint8_t*)d_dst, bytes, false, (hipStream_t)stream));
+}
+size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t bytes, void* stream)
+{
+	return byte_kernel(stenos_k_launch_delta((const uint8_t*)d_src, (uint8_t*)d_dst, bytes, true, (hipStream_t)stream));
+}
+
 void stenos_hip_set_profiling(stenos_context* ctx, int enabled) { ctx->profiling = enabled != 0; }
 double stenos_hip_kernel_ms(stenos_context* ctx, int which)
 {
@@ -1031,12 +1119,12 @@ const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb)
 size_t stenos_hip_decompress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size,
 			     const uint64_t* d_index, void* stream)
 {
-	return decompress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, d_index, nullptr, (hipStream_t)stream, true);
+	return decompress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, d_index, nullptr, nullptr, (hipStream_t)stream, true);
 }
 size_t stenos_hip_decompress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size,
 				   const uint64_t* d_index, void* stream)
 {
-	return decompress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, d_index, nullptr, (hipStream_t)stream, false);
+	return decompress_device(ctx, d_src, bytesoftype, bytes, d_dst, dst_size, d_index, nullptr, nullptr, (hipStream_t)stream, false);
 }
 
 } // extern "C"

@@ -37,3 +37,7 @@ hipError_t stenos_k_launch_resolve(const codec::FrameJob& j, hipStream_t stream)
 hipError_t stenos_k_launch_pack(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
 hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream);
 hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream);
+
+// byte_kernels.hip
+hipError_t stenos_k_launch_shuffle(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t bytes, bool inverse, hipStream_t stream);
+hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t bytes, bool inverse, hipStream_t stream);
