@@ -135,7 +135,7 @@ def run_workload(st, torch, src, T, steps, warmup, dist, world):
         dist.barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=src.device)
+        t = torch.tensor([wall], dtype=torch.float64, device=src.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     ok = bool(torch.equal(back, src))
@@ -152,10 +152,15 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
     import torch.distributed as dist
 
+    # one process per GPU; STENOS_BENCH_ONE_DEVICE=1 (test rigs with a single GPU) puts every rank on cuda:0
+    # and uses gloo for the barrier / max reduction, which are the only collectives of this benchmark
+    one_device = os.environ.get("STENOS_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_device else "nccl", rank=rank, world_size=world)
 
     from stenos_amd.api import Stenos
     from stenos_amd.datagen import generate_torch

@@ -273,6 +273,7 @@ WV_FN void pack_superblock(Lds lds, const FrameJob& j, uint64_t s, uint32_t w)
 		}
 	}
 	const uint8_t* slot0 = j.slots + first * (uint64_t)j.slot_stride;
+	const uint32_t steps = 1; // consecutive bytes: blocks are never empty, so the block index grows by at most 1 per byte
 	for (uint32_t g = g0; g < g1; g += 64) {
 		U32 gi = U32(g) + lane;
 		Pred act = gi < U32(g1);
@@ -291,44 +292,50 @@ WV_FN void pack_superblock(Lds lds, const FrameJob& j, uint64_t s, uint32_t w)
 		U32 bstart = lds_ld32(lds, bi * 4u), bend = lds_ld32(lds, (bi + 1u) * 4u);
 		Pred fast = whole & (q0 + 16u <= bend);
 		{
+			// two aligned 16-byte loads cover the 16 source bytes (slots are 16-byte aligned and padded), then a
+			// byte funnel: two wide requests per lane instead of five dword requests
 			U32 soff = bi * j.slot_stride + (q0 - bstart);
-			U32 sa = soff & ~3u, sh = (soff & 3u) << 3;
-			U32 w0 = gld32(slot0, sa, fast), w1 = gld32(slot0, sa + 4u, fast), w2 = gld32(slot0, sa + 8u, fast), w3 = gld32(slot0, sa + 12u, fast);
-			U32 w4 = gld32(slot0, sa + 16u, fast & (sh != U32(0u)));
-			U32 ish = U32(32u) - sh;
+			U32 sa = soff & ~15u;
+			U128 a = gld128(slot0, sa, fast), b = gld128(slot0, sa + 16u, fast & ((soff & 15u) != U32(0u)));
+			U32 wsel = (soff >> 2) & 3u; // first source dword inside the 32-byte window
+			U32 sh = (soff & 3u) << 3, ish = U32(32u) - sh;
+			// W[wsel .. wsel+4] out of {a.x a.y a.z a.w b.x b.y b.z b.w}
+			U32 t0 = sel(wsel == U32(0u), a.x, sel(wsel == U32(1u), a.y, sel(wsel == U32(2u), a.z, a.w)));
+			U32 t1 = sel(wsel == U32(0u), a.y, sel(wsel == U32(1u), a.z, sel(wsel == U32(2u), a.w, b.x)));
+			U32 t2 = sel(wsel == U32(0u), a.z, sel(wsel == U32(1u), a.w, sel(wsel == U32(2u), b.x, b.y)));
+			U32 t3 = sel(wsel == U32(0u), a.w, sel(wsel == U32(1u), b.x, sel(wsel == U32(2u), b.y, b.z)));
+			U32 t4 = sel(wsel == U32(0u), b.x, sel(wsel == U32(1u), b.y, sel(wsel == U32(2u), b.z, b.w)));
+			Pred al = sh == U32(0u);
 			U128 v;
-			v.x = sel(sh == U32(0u), w0, (w0 >> sh) | (w1 << ish));
-			v.y = sel(sh == U32(0u), w1, (w1 >> sh) | (w2 << ish));
-			v.z = sel(sh == U32(0u), w2, (w2 >> sh) | (w3 << ish));
-			v.w = sel(sh == U32(0u), w3, (w3 >> sh) | (w4 << ish));
+			v.x = sel(al, t0, (t0 >> sh) | (t1 << ish));
+			v.y = sel(al, t1, (t1 >> sh) | (t2 << ish));
+			v.z = sel(al, t2, (t2 >> sh) | (t3 << ish));
+			v.w = sel(al, t3, (t3 >> sh) | (t4 << ish));
 			gst128(abase, gp, v, fast);
 		}
+		// groups cut by a block boundary or by the ends of this wave's share: byte by byte, but with all
+		// table look-ups and loads of the 16 bytes issued before the first store (no dependent round trips)
 		Pred slow = act & !fast;
-		if (any(slow))
-			for (uint32_t k = 0; k < 4; ++k) { // dword k of the group
-				U32 dq = gp + U32(4 * k) - U32(mis16); // payload position of its first byte (may wrap below 0)
-				Pred din = slow & (gp + U32(4 * k) >= U32(mis16 + b0)) & (gp + U32(4 * k + 4) <= U32(mis16 + b1));
-				U32 bk = bi;
-				for (;;) {
-					Pred adv = din & (bk + 1u < U32(count)) & (dq >= lds_ld32(lds, (bk + 1u) * 4u));
-					if (!any(adv))
-						break;
+		if (any(slow)) {
+			U32 vals[16];
+			U32 bk = bi;
+			for (uint32_t c = 0; c < 16; ++c) {
+				U32 ap = gp + U32(c); // offset from abase
+				Pred ok = slow & (ap >= U32(mis16 + b0)) & (ap < U32(mis16 + b1));
+				U32 p = sel(ok, ap - U32(mis16), q0);
+				// the block of byte p is at most `steps` blocks after the block of the previous byte
+				for (uint32_t st = 0; st < steps; ++st) {
+					Pred adv = ok & (bk + 1u < U32(count)) & (p >= lds_ld32(lds, (bk + 1u) * 4u));
 					bk = sel(adv, bk + 1u, bk);
 				}
-				Pred dfast = din & (dq + 4u <= lds_ld32(lds, (bk + 1u) * 4u));
-				U32 soff = bk * j.slot_stride + (dq - lds_ld32(lds, bk * 4u));
-				U32 sa = soff & ~3u, sh = (soff & 3u) << 3;
-				U32 w0 = gld32(slot0, sa, dfast), w1 = gld32(slot0, sa + 4u, dfast & (sh != U32(0u)));
-				gst32(abase, gp + U32(4 * k), sel(sh == U32(0u), w0, (w0 >> sh) | (w1 << (U32(32u) - sh))), dfast);
-				Pred dslow = slow & !dfast;
-				if (any(dslow))
-					for (uint32_t c = 0; c < 4; ++c) {
-						U32 ap = gp + U32(4 * k + c); // offset from abase
-						Pred ok = dslow & (ap >= U32(mis16 + b0)) & (ap < U32(mis16 + b1));
-						U32 byte = pack_src_byte(j, lds, first, sel(ok, ap - U32(mis16), U32(0u)), bi, count, ok);
-						gst8(abase, ap, byte, ok);
-					}
+				vals[c] = gld8(slot0, bk * j.slot_stride + (p - lds_ld32(lds, bk * 4u)), ok);
 			}
+			for (uint32_t c = 0; c < 16; ++c) {
+				U32 ap = gp + U32(c);
+				Pred ok = slow & (ap >= U32(mis16 + b0)) & (ap < U32(mis16 + b1));
+				gst8(abase, ap, vals[c], ok);
+			}
+		}
 		lo = readlane(bi, 0); // the next iteration starts at or after this lane's block
 	}
 }
