@@ -590,7 +590,14 @@ static size_t partial_compress(const uint8_t* src, size_t T, size_t n, uint8_t* 
 /* block_compress, block_compress.h:1099-1302, block_level 2, no time limit, not pre-shuffled,
  * no target ratio.  Capacity arithmetic is done on offsets (the reference compares pointers that
  * may run past dst_end). */
+static size_t block_compress_target(const uint8_t* src, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, const double* target_ratio);
 size_t so_block_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* dst, size_t dst_size)
+{
+	return block_compress_target(src, T, bytes, dst, dst_size, NULL);
+}
+/* target_ratio: block_compress.h:1266-1274 -- once 1/16 of the input has been consumed the running ratio must
+ * reach *target_ratio, else the call fails (the caller then tries the zstd strategies) */
+static size_t block_compress_target(const uint8_t* src, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, const double* target_ratio)
 {
 	if (bytes == 0)
 		return 0;
@@ -618,7 +625,7 @@ size_t so_block_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* ds
 					dst[anchor] = SO_BLOCK_LZ;
 					memcpy(dst + anchor + 1, tmp, n);
 					off = anchor + 1 + n;
-					continue;
+					goto marker;
 				}
 			}
 		}
@@ -650,6 +657,15 @@ size_t so_block_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* ds
 			size_t n = (size_t)(emit_planes(block, T, infos, tmp) - tmp);
 			memcpy(dst + anchor, tmp, n);
 			off = anchor + n;
+		}
+	marker:
+		if (target_ratio && (b + 1) * bs >= bytes / 16) {
+			double ratio = (double)((b + 1) * bs) / (double)off;
+			if (ratio < *target_ratio) {
+				result = SO_ERROR_DST_OVERFLOW;
+				goto done;
+			}
+			target_ratio = NULL;
 		}
 	}
 	{
@@ -920,9 +936,11 @@ size_t so_block_decompress(const uint8_t* src, size_t size, size_t T, size_t byt
 typedef size_t (*zstd_compress_fn)(void*, size_t, const void*, size_t, int);
 typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
 typedef unsigned (*zstd_iserror_fn)(size_t);
+typedef int (*zstd_maxclevel_fn)(void);
 static zstd_compress_fn z_compress;
 static zstd_decompress_fn z_decompress;
 static zstd_iserror_fn z_iserror;
+static zstd_maxclevel_fn z_maxclevel;
 
 static int load_zstd(void)
 {
@@ -937,9 +955,144 @@ static int load_zstd(void)
 		z_compress = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
 		z_decompress = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
 		z_iserror = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+		z_maxclevel = (zstd_maxclevel_fn)dlsym(h, "ZSTD_maxCLevel");
 	}
-	state = (z_compress && z_decompress && z_iserror) ? 1 : -1;
+	state = (z_compress && z_decompress && z_iserror && z_maxclevel) ? 1 : -1;
 	return state > 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * LZ4 "dry" size estimator (lz4dry.cpp:658-848): LZ4-fast with a 256-entry position table
+ * (LZ4_MEMORY_USAGE 10, :117, 141), counting the bytes a real LZ4 stream would take
+ * ---------------------------------------------------------------------------------------- */
+
+static uint32_t rd32(const uint8_t* p)
+{
+	return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static unsigned lz4_hash(uint32_t seq) { return (seq * 2654435761U) >> 24; } /* LZ4_hash4, byU32, hash log 8 */
+
+static size_t lz4_dry_size(const uint8_t* src, size_t n_in, int accel)
+{
+	const int MINMATCH = 4, MFLIMIT = 12, LASTLITERALS = 5, MAXD = 65535, ML_MASK = 15, RUN_MASK = 15;
+	int n = (int)n_in;
+	uint32_t table[256];
+	memset(table, 0, sizeof(table)); /* LZ4_resetStream, lz4dry.cpp:815-819 */
+	if (accel < 1)
+		accel = 1;
+	if ((uint32_t)n > 0x7E000000u)
+		return 0;
+	int ip = 0, anchor = 0, count = 0;
+	const int iend = n, mflimit = n - MFLIMIT, matchlimit = n - LASTLITERALS;
+	if (n >= MFLIMIT + 1) {
+		table[lz4_hash(rd32(src))] = 0;
+		ip = 1;
+		unsigned forward_h = lz4_hash(rd32(src + ip));
+		for (;;) {
+			int match;
+			{ /* find a match, :705-722 */
+				int forward_ip = ip;
+				unsigned step = 1, search_nb = (unsigned)accel << 6;
+				for (;;) {
+					unsigned h = forward_h;
+					ip = forward_ip;
+					forward_ip += (int)step;
+					step = search_nb++ >> 6;
+					if (forward_ip > mflimit)
+						goto last_literals;
+					match = (int)table[h];
+					forward_h = lz4_hash(rd32(src + forward_ip));
+					table[h] = (uint32_t)ip;
+					if (!(match + MAXD < ip) && rd32(src + match) == rd32(src + ip))
+						break;
+				}
+			}
+			while (ip > anchor && match > 0 && src[ip - 1] == src[match - 1]) { /* catch up, :725-728 */
+				ip--;
+				match--;
+			}
+			{ /* literals, :731-745 */
+				int lit = ip - anchor;
+				count++;
+				if (lit >= RUN_MASK)
+					count += 1 + (lit - RUN_MASK) / 256;
+				count += lit;
+			}
+			for (;;) { /* _next_match, :747-793 */
+				count += 2;
+				int m = 0;
+				{
+					const uint8_t* a = src + ip + MINMATCH;
+					const uint8_t* b = src + match + MINMATCH;
+					const uint8_t* lim = src + matchlimit;
+					while (a + m < lim && a[m] == b[m])
+						++m;
+				}
+				ip += MINMATCH + m;
+				if (m >= ML_MASK) {
+					m -= ML_MASK;
+					while (m >= 4 * 255) {
+						count += 4;
+						m -= 4 * 255;
+					}
+					count += 1 + m / 255;
+				}
+				anchor = ip;
+				if (ip > mflimit)
+					goto last_literals;
+				table[lz4_hash(rd32(src + ip - 2))] = (uint32_t)(ip - 2);
+				match = (int)table[lz4_hash(rd32(src + ip))];
+				table[lz4_hash(rd32(src + ip))] = (uint32_t)ip;
+				if (match + MAXD >= ip && rd32(src + match) == rd32(src + ip)) {
+					++count;
+					continue;
+				}
+				break;
+			}
+			forward_h = lz4_hash(rd32(src + ++ip));
+		}
+	}
+last_literals: { /* :795-813 */
+	int last = iend - anchor;
+	if (last >= RUN_MASK)
+		count += 2 + (last - RUN_MASK) / 256;
+	else
+		++count;
+	count += last;
+}
+	return (size_t)count;
+}
+
+/* guess_transposed_lz_ratio, stenos.cpp:376-401 */
+static double transposed_lz_ratio(const uint8_t* shuffled, size_t T, size_t bytes, int level, int with_delta)
+{
+	size_t elements = bytes / T;
+	size_t step = elements / (size_t)(16 / (level - 1));
+	if (step < 64)
+		step = elements;
+	size_t csize = 0, processed = 0;
+	uint8_t* tmp = with_delta ? (uint8_t*)malloc(step + 1) : NULL;
+	for (size_t i = 0; i < T; ++i) {
+		const uint8_t* in = shuffled + i * elements + (elements - step) / 2;
+		if (with_delta) {
+			so_delta(in, tmp, step);
+			in = tmp;
+		}
+		csize += lz4_dry_size(in, step, 10 - level);
+		processed += step;
+	}
+	free(tmp);
+	return ((double)processed / (double)csize) * (1. + (double)level * 0.02);
+}
+
+/* zstd_from_reduced_level, zstd_wrapper.h:49-56 */
+static int zstd_level_of(int clevel)
+{
+	if (clevel < 1)
+		return 1;
+	if (clevel < 9)
+		return clevel * 2 - 1;
+	return z_maxclevel();
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -980,12 +1133,105 @@ static size_t sb_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* d
 		put_le(dst + 1, r, 3);
 		return r + 4;
 	}
-	size_t r = so_block_compress(src, T, bytes, dst + 4, dst_size - 4);
-	if (so_has_error(r) || r > bytes) /* equal is kept, :609 */
-		return sb_copy(src, bytes, dst, dst_size);
-	dst[0] = 1;
-	put_le(dst + 1, r, 3);
-	return r + 4;
+	if (T > 1 && level < 2) { /* BLOCK, :449-450, 606-615 */
+		size_t r = so_block_compress(src, T, bytes, dst + 4, dst_size - 4);
+		if (so_has_error(r) || r > bytes) /* equal is kept, :609 */
+			return sb_copy(src, bytes, dst, dst_size);
+		dst[0] = 1;
+		put_le(dst + 1, r, 3);
+		return r + 4;
+	}
+	/* levels >= 2 and bytesoftype 1: block codec and/or zstd, stenos.cpp:451-604, 617-678 */
+	if (!load_zstd())
+		return SO_ERROR_ZSTD_INTERNAL;
+	int zstd_level = level;
+	if (T > 1) {
+		zstd_level = level - 1;
+		if (zstd_level >= 4)
+			++zstd_level;
+	}
+	const int zl = zstd_level_of(zstd_level);
+	double lz_ratio = 1.1, lz_tr = 0, lz_trd = 0;
+	if (bytes >= T * 256)
+		lz_ratio = (double)(bytes / 16) / (double)lz4_dry_size(src, bytes / 16, 10 - level);
+	uint8_t* b1 = (uint8_t*)malloc(bytes + 64);
+	uint8_t* b2 = (uint8_t*)malloc(bytes + 64);
+	if (!b1 || !b2) {
+		free(b1);
+		free(b2);
+		return SO_ERROR_ALLOC;
+	}
+	size_t ret;
+	int code = 0;
+	const uint8_t* zsrc = src;
+	if (T > 1) {
+		so_shuffle(T, bytes, src, b1);
+		if (bytes >= T * 256 && level > 2) {
+			lz_tr = transposed_lz_ratio(b1, T, bytes, level, 0);
+			if (lz_tr > lz_ratio)
+				lz_ratio = lz_tr;
+			lz_trd = transposed_lz_ratio(b1, T, bytes, level, 1) * 1.1;
+			if (lz_trd > lz_ratio)
+				lz_ratio = lz_trd;
+			const double factor = 1. + level / 12.;
+			lz_tr *= factor;
+			lz_trd *= factor;
+			lz_ratio *= factor;
+		}
+	}
+	else
+		lz_ratio *= 1. + level / 12.;
+	{
+		size_t cblock = block_compress_target(src, T, bytes, b2, bytes, &lz_ratio);
+		if (so_has_error(cblock) || cblock > bytes) {
+			code = 2;
+			if (lz_ratio > 1.40) {
+				if (lz_ratio == lz_tr)
+					code = 3;
+				else if (lz_ratio == lz_trd)
+					code = 4;
+			}
+		}
+		else {
+			size_t r = z_compress(dst + 4, dst_size - 4, b2, cblock, zl);
+			if (z_iserror(r) || r > cblock) { /* NO_ZSTD, :585-596 */
+				if (dst_size < 4 + cblock)
+					ret = SO_ERROR_DST_OVERFLOW;
+				else {
+					dst[0] = 1;
+					put_le(dst + 1, cblock, 3);
+					memcpy(dst + 4, b2, cblock);
+					ret = cblock + 4;
+				}
+			}
+			else {
+				dst[0] = 5;
+				put_le(dst + 1, r, 3);
+				ret = r + 4;
+			}
+			goto out;
+		}
+	}
+	if (code == 3)
+		zsrc = b1;
+	else if (code == 4) {
+		so_delta(b1, b2, bytes);
+		zsrc = b2;
+	}
+	{
+		size_t r = z_compress(dst + 4, dst_size - 4, zsrc, bytes, zl);
+		if (z_iserror(r) || r > bytes)
+			ret = sb_copy(src, bytes, dst, dst_size);
+		else {
+			dst[0] = (uint8_t)code;
+			put_le(dst + 1, r, 3);
+			ret = r + 4;
+		}
+	}
+out:
+	free(b1);
+	free(b2);
+	return ret;
 }
 
 /* stenos_compress -> stenos_compress_generic serial path, stenos.cpp:844-907, 1210-1218 */
@@ -997,8 +1243,6 @@ size_t so_compress(const void* _src, size_t T, size_t bytes, void* _dst, size_t 
 	if (level < 0) level = 0;
 	if (T == 0 || T >= MAX_BYTESOFTYPE) /* :119-120 */
 		return SO_ERROR_INVALID_BYTESOFTYPE;
-	if (level > 1 || T == 1)
-		return SO_ERROR_INVALID_PARAMETER; /* outside the oracle's scope (see header) */
 	size_t bs = 256 * T, sb = base_superblock(bs);
 	unsigned shift = 0;
 	if (bytes > sb) {

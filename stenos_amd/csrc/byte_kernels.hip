@@ -179,6 +179,62 @@ __global__ __launch_bounds__(256) void delta_inv_kernel(const uint8_t* __restric
 	}
 }
 
+// All superblocks of a buffer at once: superblock s = bytes [s*sb, min((s+1)*sb, total)) is shuffled on its own
+// (stenos.cpp:513), tiles_per_sb workgroups each.
+__global__ __launch_bounds__(TILE_THREADS) void shuffle_superblocks_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t T,
+									    uint64_t sb, uint64_t total, uint32_t E, uint32_t tiles_per_sb)
+{
+	const uint64_t s = blockIdx.x / tiles_per_sb;
+	const uint32_t tix = blockIdx.x % tiles_per_sb;
+	const uint64_t begin = s * sb;
+	const uint64_t bytes = (total - begin) < sb ? (total - begin) : sb;
+	const uint64_t n = bytes / T;
+	const uint64_t e0 = (uint64_t)tix * E;
+	const uint8_t* sp = src + begin;
+	uint8_t* dp = dst + begin;
+	if (tix == 0) { // leftover bytes of the superblock
+		const uint64_t rem = bytes - n * T;
+		for (uint64_t o = threadIdx.x; o < rem; o += TILE_THREADS)
+			dp[n * T + o] = sp[n * T + o];
+	}
+	if (e0 >= n)
+		return;
+	const uint32_t cnt = (uint32_t)((n - e0) < E ? (n - e0) : E);
+	const uint32_t tb = cnt * T;
+	const uint8_t* t0 = sp + e0 * T;
+	for (uint32_t o = threadIdx.x; o < tb; o += TILE_THREADS)
+		tile[o] = t0[o];
+	__syncthreads();
+	for (uint32_t j = 0; j < T; ++j) {
+		uint8_t* d = dp + (uint64_t)j * n + e0;
+		for (uint32_t e = threadIdx.x; e < cnt; e += TILE_THREADS)
+			d[e] = tile[e * T + j];
+	}
+}
+
+// Byte delta (delta.cpp:30-71) of the `step` bytes around the middle of every byte plane of every shuffled
+// superblock: the input of guess_transposed_lz_ratio (stenos.cpp:388-392).  One workgroup per (superblock, plane);
+// out receives the T pieces of superblock s back to back at s*sb.
+__global__ __launch_bounds__(256) void delta_middles_kernel(const uint8_t* __restrict__ shuffled, uint8_t* __restrict__ out, uint32_t T, uint64_t sb,
+							     uint64_t total, uint32_t level, uint32_t with_delta)
+{
+	const uint64_t s = blockIdx.x / T;
+	const uint32_t i = blockIdx.x % T;
+	const uint64_t begin = s * sb;
+	const uint64_t bytes = (total - begin) < sb ? (total - begin) : sb;
+	const uint64_t elements = bytes / T;
+	uint64_t step = elements / (16 / (level - 1));
+	if (step < 64)
+		step = elements;
+	const uint8_t* in = shuffled + begin + i * elements + (elements - step) / 2;
+	uint8_t* o = out + begin + i * step;
+	const uint64_t q = step / 4;
+	for (uint64_t k = threadIdx.x; k < step; k += 256) {
+		const bool start = !with_delta || delta_is_start(k, step, q);
+		o[k] = start ? in[k] : (uint8_t)(in[k] - in[k - 1]);
+	}
+}
+
 uint32_t tile_elements(uint32_t T)
 {
 	uint32_t e = (48u * 1024u) / T;
@@ -225,5 +281,32 @@ hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t byte
 		hipLaunchKernelGGL(delta_inv_kernel, dim3(bytes <= 2048 ? 1 : 4), dim3(256), 0, stream, src, dst, bytes);
 	else
 		hipLaunchKernelGGL(delta_kernel, dim3((uint32_t)((bytes + 4095) / 4096)), dim3(256), 0, stream, src, dst, bytes);
+	return hipGetLastError();
+}
+
+hipError_t stenos_k_launch_shuffle_superblocks(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t sb, uint64_t total, hipStream_t stream)
+{
+	if (total == 0)
+		return hipSuccess;
+	if (T == 1)
+		return hipMemcpyAsync(dst, src, total, hipMemcpyDeviceToDevice, stream);
+	const uint32_t E = tile_elements(T);
+	const uint64_t nsb = (total + sb - 1) / sb;
+	const uint32_t tiles = (uint32_t)((sb / T + E - 1) / E);
+	const size_t lds = (size_t)E * T;
+	hipError_t e = hipFuncSetAttribute((const void*)shuffle_superblocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(shuffle_superblocks_kernel, dim3((uint32_t)(nsb * tiles)), dim3(TILE_THREADS), lds, stream, src, dst, T, sb, total, E, tiles);
+	return hipGetLastError();
+}
+
+hipError_t stenos_k_launch_delta_middles(const uint8_t* shuffled, uint8_t* out, uint32_t T, uint64_t sb, uint64_t total, uint32_t level, bool with_delta,
+					 hipStream_t stream)
+{
+	if (total == 0)
+		return hipSuccess;
+	const uint64_t nsb = (total + sb - 1) / sb;
+	hipLaunchKernelGGL(delta_middles_kernel, dim3((uint32_t)(nsb * T)), dim3(256), 0, stream, shuffled, out, T, sb, total, level, with_delta ? 1u : 0u);
 	return hipGetLastError();
 }

@@ -20,6 +20,7 @@
 
 #include "../../include/stenos_hip.h"
 #include "kernels.h"
+#include "strategy.h"
 
 namespace {
 
@@ -31,7 +32,9 @@ inline bool is_err(size_t r) { return r >= STENOS_LAST_ERROR_CODE; }
 typedef size_t (*zstd_compress_fn)(void*, size_t, const void*, size_t, int);
 typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
 typedef unsigned (*zstd_iserror_fn)(size_t);
+typedef int (*zstd_maxclevel_fn)(void);
 struct Zstd {
+	zstd_maxclevel_fn max_level = nullptr;
 	zstd_compress_fn compress = nullptr;
 	zstd_decompress_fn decompress = nullptr;
 	zstd_iserror_fn is_error = nullptr;
@@ -47,7 +50,8 @@ struct Zstd {
 		compress = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
 		decompress = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
 		is_error = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
-		ok = compress && decompress && is_error;
+		max_level = (zstd_maxclevel_fn)dlsym(h, "ZSTD_maxCLevel");
+		ok = compress && decompress && is_error && max_level;
 	}
 };
 Zstd& zstd()
@@ -124,6 +128,7 @@ struct stenos_context_s {
 	DevBuf in, out;                                  // staging for the host-pointer ABI
 	DevBuf slots, bsize, binfo, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
+	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [24,32) scan carry, [64,320) override payload
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
@@ -161,7 +166,7 @@ struct stenos_context_s {
 	}
 	~stenos_context_s()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2 };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1 };
 		for (DevBuf* b : all)
 			b->release();
 		if (h_total)
@@ -233,12 +238,12 @@ size_t check_supported(const stenos_context_s* ctx, size_t T, int level)
 {
 	if (ctx->max_nanoseconds) // time-limited mode: wall-clock dependent output
 		return STENOS_ERROR_INVALID_PARAMETER;
-	if (level > 1) // levels >= 2 need the lz4-dry estimator + zstd orchestration
-		return STENOS_ERROR_INVALID_PARAMETER;
-	if (level == 1 && (T == 1 || T > kMaxT))
+	if (level >= 1 && T > kMaxT) // the block does not fit the per-wave LDS budget of the codec
 		return STENOS_ERROR_INVALID_PARAMETER;
 	return 0;
 }
+// levels >= 2 and bytesoftype 1 go through the strategy layer (block codec on the GPU + zstd on the host)
+inline bool needs_strategy(size_t T, int level) { return level >= 2 || (level == 1 && T == 1); }
 
 // Enqueue the compression of `bytes` device bytes into a frame (or, with frame_header == false, into
 // the bare superblock stream used by the private API).  Nothing is waited for except, for a final
@@ -292,6 +297,8 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	j.override_code = 0;
 
 	j.check_total = 0;
+	j.fixed_capacity = 0;
+	j.qprod = nullptr;
 	const uint64_t header = j.header_bytes;
 
 	// Superblocks whose capacity is certainly large enough for any encoding ("safe zone", normally all but the
@@ -406,6 +413,234 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	return 0;
 }
 
+// zstd_from_reduced_level (zstd_wrapper.h:49-56)
+int zstd_level_of(int clevel)
+{
+	if (clevel < 1)
+		return 1;
+	if (clevel < 9)
+		return clevel * 2 - 1;
+	return zstd().max_level();
+}
+
+// compress_memcpy (stenos.cpp:363-374) into host memory
+size_t host_copy_superblock(const uint8_t* src, size_t bytes, uint8_t* dst, size_t room)
+{
+	if (room < bytes + 4)
+		return STENOS_ERROR_DST_OVERFLOW;
+	dst[0] = 6;
+	put_le(dst + 1, bytes, 3);
+	memcpy(dst + 4, src, bytes);
+	return bytes + 4;
+}
+
+// Levels >= 2 and bytesoftype 1: the strategy layer of compress_generic_superblock (stenos.cpp:451-604, 617-678).
+// The GPU encodes every superblock with the block codec (capacity = the superblock's own size, as the reference's
+// scratch buffer), shuffles the input and prepares the plane middles for the LZ4-dry estimates; the host runs
+// the estimator and zstd (third-party entropy coder) and assembles the frame in `h_dst` with the reference's
+// serial capacity semantics.  h_src / d_src: host and device copies of the input.
+size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint8_t* d_src, size_t T, size_t bytes, uint8_t* h_dst, size_t dst_size,
+			 int level, const FramePlan& f, hipStream_t stream)
+{
+	if (!zstd().ok)
+		return STENOS_ERROR_ZSTD_INTERNAL;
+	if (dst_size < f.header)
+		return STENOS_ERROR_DST_OVERFLOW;
+	h_dst[0] = (uint8_t)f.shift;
+	put_le(h_dst + 1, bytes, 7);
+	if (f.header == 12)
+		put_le(h_dst + 8, f.sb, 4);
+	const uint64_t nblocks = f.nfull + (f.tail ? 1 : 0);
+	const uint32_t stride = stenos_k_slot_stride((uint32_t)T);
+	const size_t tmp_cap = bytes + 4 * (size_t)f.nsb + 64;
+	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
+	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
+	    !ctx->sboff.ensure((f.nsb + 2) * 8) || !ctx->misc.ensure(4096) || !ctx->qprod.ensure((f.nsb + 1) * 4) ||
+	    !ctx->slots.ensure((nblocks + 1) * (size_t)stride) || !ctx->tmp1.ensure(tmp_cap))
+		return STENOS_ERROR_ALLOC;
+	uint8_t* misc = ctx->misc.as<uint8_t>();
+	codec::FrameJob j;
+	memset(&j, 0, sizeof(j));
+	j.src = d_src;
+	j.dst = ctx->tmp1.as<uint8_t>();
+	j.dst_size = ~(uint64_t)0 >> 1;
+	j.slots = ctx->slots.as<uint8_t>();
+	j.bsize = ctx->bsize.as<uint32_t>();
+	j.binfo = ctx->binfo.as<uint32_t>();
+	j.boff = ctx->boff.as<uint32_t>();
+	j.sb_csize = ctx->sbcsize.as<uint32_t>();
+	j.sb_code = ctx->sbcode.as<uint8_t>();
+	j.sb_need = ctx->sbneed.as<uint32_t>();
+	j.sb_off = ctx->sboff.as<uint64_t>();
+	j.total = (uint64_t*)misc;
+	j.status = (uint32_t*)(misc + 12);
+	j.first_flagged = (uint32_t*)(misc + 16);
+	j.override_payload = misc + 64;
+	j.nfull = f.nfull;
+	j.nsb = f.nsb;
+	j.total_bytes = bytes;
+	j.tail_bytes = f.tail;
+	j.bps = f.bps;
+	j.sb_bytes = (uint32_t)f.sb;
+	j.slot_stride = stride;
+	j.T = (uint32_t)T;
+	j.shift_byte = 0xFFFFFFFFu;
+	j.fixed_capacity = 1;
+	j.qprod = ctx->qprod.as<uint32_t>();
+	uint64_t* d_carry = (uint64_t*)(misc + 24);
+	const uint32_t init[2] = { 0u, 0xFFFFFFFFu };
+	const uint64_t zero = 0;
+	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	    hipMemcpyAsync(d_carry, &zero, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	    hipMemcpyAsync(j.total, &zero, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	    stenos_k_launch_encode(j, 0, nblocks, stream) != hipSuccess || stenos_k_launch_plan(j, 0, f.nsb, stream) != hipSuccess ||
+	    stenos_k_launch_scan(j, 0, f.nsb, d_carry, stream) != hipSuccess || stenos_k_launch_pack(j, 0, f.nsb, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	std::vector<uint8_t> code(f.nsb);
+	std::vector<uint32_t> csize(f.nsb), qprod(f.nsb);
+	std::vector<uint64_t> sboff(f.nsb + 1);
+	if (hipMemcpyAsync(code.data(), j.sb_code, f.nsb, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	    hipMemcpyAsync(csize.data(), j.sb_csize, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	    hipMemcpyAsync(qprod.data(), j.qprod, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	    hipMemcpyAsync(sboff.data(), j.sb_off, (f.nsb + 1) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	    hipStreamSynchronize(stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	std::vector<uint8_t> blocks((size_t)sboff[f.nsb]);
+	if (!blocks.empty() && hipMemcpy(blocks.data(), j.dst, blocks.size(), hipMemcpyDeviceToHost) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
+	// transposed views for the estimator and the transposed zstd strategies (levels > 2 only, stenos.cpp:515-537)
+	const bool transposed = T > 1 && level > 2;
+	std::vector<uint8_t> shuf, mid0, mid1, delta_full;
+	if (transposed) {
+		if (!ctx->shuf.ensure(bytes + 64) || !ctx->mid0.ensure(bytes + 64) || !ctx->mid1.ensure(bytes + 64))
+			return STENOS_ERROR_ALLOC;
+		if (stenos_k_launch_shuffle_superblocks(d_src, ctx->shuf.as<uint8_t>(), (uint32_t)T, f.sb, bytes, stream) != hipSuccess ||
+		    stenos_k_launch_delta_middles(ctx->shuf.as<uint8_t>(), ctx->mid0.as<uint8_t>(), (uint32_t)T, f.sb, bytes, (uint32_t)level, false, stream) != hipSuccess ||
+		    stenos_k_launch_delta_middles(ctx->shuf.as<uint8_t>(), ctx->mid1.as<uint8_t>(), (uint32_t)T, f.sb, bytes, (uint32_t)level, true, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		shuf.resize(bytes);
+		mid0.resize(bytes);
+		mid1.resize(bytes);
+		if (hipMemcpy(shuf.data(), ctx->shuf.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+		    hipMemcpy(mid0.data(), ctx->mid0.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+		    hipMemcpy(mid1.data(), ctx->mid1.p, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+	}
+
+	int zstd_level = level; // stenos.cpp:441-460
+	if (T > 1) {
+		zstd_level = level - 1;
+		if (zstd_level >= 4)
+			++zstd_level;
+	}
+	const int zl = zstd_level_of(zstd_level);
+	const size_t bs = 256 * T;
+	size_t off = f.header;
+	for (uint64_t s = 0; s < f.nsb; ++s) {
+		if (dst_size < off + 4) // stenos.cpp:427-429
+			return STENOS_ERROR_DST_OVERFLOW;
+		const size_t room = dst_size - off;
+		const uint8_t* src = h_src + s * f.sb;
+		const size_t sbytes = (size_t)((bytes - s * f.sb) < f.sb ? (bytes - s * f.sb) : f.sb);
+		uint8_t* out = h_dst + off;
+		size_t r;
+		if (sbytes < 128) { // small input: direct zstd with zstd level 1 (stenos.cpp:435-437)
+			r = zstd().compress(out + 4, room - 4, src, sbytes, 1);
+			if (zstd().is_error(r) || r > sbytes)
+				r = host_copy_superblock(src, sbytes, out, room);
+			else {
+				out[0] = 2;
+				put_le(out + 1, r, 3);
+				r += 4;
+			}
+		}
+		else {
+			double lz_ratio = 1.1, lz_tr = 0, lz_trd = 0;
+			if (sbytes >= bs)
+				lz_ratio = (double)(sbytes / 16) / (double)strategy::lz4_dry_size(src, sbytes / 16, 10 - level);
+			if (T > 1) {
+				if (transposed && sbytes >= bs) {
+					const size_t step = strategy::middle_step(T, sbytes, level);
+					lz_tr = strategy::transposed_ratio(mid0.data() + s * f.sb, T, step, level);
+					if (lz_tr > lz_ratio)
+						lz_ratio = lz_tr;
+					lz_trd = strategy::transposed_ratio(mid1.data() + s * f.sb, T, step, level) * 1.1;
+					if (lz_trd > lz_ratio)
+						lz_ratio = lz_trd;
+					const double factor = 1. + level / 12.;
+					lz_tr *= factor;
+					lz_trd *= factor;
+					lz_ratio *= factor;
+				}
+			}
+			else
+				lz_ratio *= 1. + level / 12.;
+			// block codec result of the GPU; the reference gives up when, after 1/16 of the input, the running
+			// ratio is below the estimate (block_compress.h:1266-1274)
+			bool ok = code[s] == 1;
+			if (ok && qprod[s]) {
+				size_t bq = (sbytes / 16 + bs - 1) / bs;
+				bq = bq == 0 ? 0 : bq - 1;
+				const double ratio = (double)((bq + 1) * bs) / (double)qprod[s];
+				if (ratio < lz_ratio)
+					ok = false;
+			}
+			if (ok) {
+				const uint8_t* payload = blocks.data() + sboff[s] + 4;
+				const size_t cblock = csize[s];
+				r = zstd().compress(out + 4, room - 4, payload, cblock, zl); // stenos.cpp:583
+				if (zstd().is_error(r) || r > cblock) {                     // NO_ZSTD (:585-596)
+					if (room < 4 + cblock)
+						return STENOS_ERROR_DST_OVERFLOW;
+					out[0] = 1;
+					put_le(out + 1, cblock, 3);
+					memcpy(out + 4, payload, cblock);
+					r = cblock + 4;
+				}
+				else {
+					out[0] = 5;
+					put_le(out + 1, r, 3);
+					r += 4;
+				}
+			}
+			else {
+				int c = 2; // stenos.cpp:548-558
+				if (lz_ratio > 1.40) {
+					if (lz_ratio == lz_tr)
+						c = 3;
+					else if (lz_ratio == lz_trd)
+						c = 4;
+				}
+				const uint8_t* zsrc = src;
+				if (c == 3)
+					zsrc = shuf.data() + s * f.sb;
+				else if (c == 4) { // byte delta of the whole transposed superblock on the GPU (stenos.cpp:646)
+					if (!ctx->tmp2.ensure(sbytes + 64))
+						return STENOS_ERROR_ALLOC;
+					delta_full.resize(sbytes);
+					if (stenos_k_launch_delta(ctx->shuf.as<uint8_t>() + s * f.sb, ctx->tmp2.as<uint8_t>(), sbytes, false, stream) != hipSuccess ||
+					    hipMemcpyAsync(delta_full.data(), ctx->tmp2.p, sbytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+					    hipStreamSynchronize(stream) != hipSuccess)
+						return STENOS_ERROR_UNDEFINED;
+					zsrc = delta_full.data();
+				}
+				r = zstd().compress(out + 4, room - 4, zsrc, sbytes, zl);
+				if (zstd().is_error(r) || r > sbytes)
+					r = host_copy_superblock(src, sbytes, out, room);
+				else {
+					out[0] = (uint8_t)c;
+					put_le(out + 1, r, 3);
+					r += 4;
+				}
+			}
+		}
+		if (is_err(r))
+			return r;
+		off += r;
+	}
+	return off;
+}
+
 size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_t bytes, void* d_dst, size_t dst_size, hipStream_t stream, bool wait)
 {
 	if (!ctx->device_ready())
@@ -421,6 +656,26 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 	if (dst_size < f.header) // stenos.cpp:862-863, 870-871
 		return STENOS_ERROR_DST_OVERFLOW;
 	ctx->job_kind = 0;
+	if (bytes && needs_strategy(T, level)) {
+		// the strategy layer needs the input on the host (estimator, zstd): fetch it, assemble the frame there
+		const size_t roomy = stenos_bound(bytes) + f.sb / 128 + 4096; // beyond ZSTD_compressBound of a superblock the capacity no longer matters
+		const size_t cap = dst_size < roomy ? dst_size : roomy;
+		std::vector<uint8_t> h_src(bytes), h_out(cap);
+		if (hipMemcpyAsync(h_src.data(), d_src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		size_t r = compress_strategy(ctx, h_src.data(), (const uint8_t*)d_src, T, bytes, h_out.data(), cap, level, f, stream);
+		if (is_err(r))
+			return r;
+		if (hipMemcpyAsync(d_dst, h_out.data(), r, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		ctx->last_nsb = 0; // no device-side index for these frames
+		ctx->h_total[0] = r;
+		ctx->h_total[1] = 0;
+		ctx->job_kind = 1;
+		ctx->job_stream = stream;
+		ctx->job_dst_size = dst_size;
+		return wait ? finish_job(ctx) : 0;
+	}
 	if (bytes == 0) { // stenos.cpp:876-878
 		uint8_t h[12];
 		h[0] = (uint8_t)f.shift;
@@ -740,6 +995,8 @@ size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t byte
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	if (needs_strategy(bytesoftype, ctx->level))
+		return compress_strategy(ctx, (const uint8_t*)src, ctx->in.as<uint8_t>(), bytesoftype, bytes, out, dst_size, ctx->level, f, nullptr);
 	// the device buffer holds `bound` bytes, which every frame fits; the caller's dst_size is the logical
 	// capacity (a frame that does not fit is reported, nothing is written past dst_size)
 	size_t r = compress_device(ctx, ctx->in.p, bytesoftype, bytes, ctx->out.p, dst_size, nullptr, true);
@@ -894,6 +1151,8 @@ size_t stenos_private_compress_block(stenos_context* ctx, const void* src, size_
 	size_t e = check_supported(ctx, bytesoftype, ctx->level);
 	if (is_err(e))
 		return e;
+	if (needs_strategy(bytesoftype, ctx->level)) // single-superblock strategy calls: not wired yet (cvector at levels >= 2)
+		return STENOS_ERROR_INVALID_PARAMETER;
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
 	if (bytes > super_block_size || super_block_size >= STENOS_MAX_BLOCK_BYTES)

@@ -41,3 +41,6 @@ hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream);
 // byte_kernels.hip
 hipError_t stenos_k_launch_shuffle(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t bytes, bool inverse, hipStream_t stream);
 hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t bytes, bool inverse, hipStream_t stream);
+hipError_t stenos_k_launch_shuffle_superblocks(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t sb, uint64_t total, hipStream_t stream);
+hipError_t stenos_k_launch_delta_middles(const uint8_t* shuffled, uint8_t* out, uint32_t T, uint64_t sb, uint64_t total, uint32_t level, bool with_delta,
+					 hipStream_t stream);

@@ -48,7 +48,11 @@ __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ 
 }
 
 // One wavefront per superblock.
-__global__ __launch_bounds__(64) void plan_superblocks(FrameJob j, uint64_t s_begin) { plan_superblock(j, s_begin + blockIdx.x); }
+__global__ __launch_bounds__(64) void plan_superblocks(FrameJob j, uint64_t s_begin)
+{
+	const Layout L = make_layout(j.T, true);
+	plan_superblock(g_lds, L, j, s_begin + blockIdx.x);
+}
 
 // Exclusive scan of (csize + 4) over superblocks [s_begin, s_begin + n) by one workgroup of 1024 threads.
 // *carry holds the frame offset of superblock s_begin on entry and of s_begin + n on exit, so consecutive
@@ -236,7 +240,14 @@ hipError_t stenos_k_launch_plan(const FrameJob& j, uint64_t s_begin, uint64_t s_
 {
 	if (s_end <= s_begin)
 		return hipSuccess;
-	hipLaunchKernelGGL(plan_superblocks, dim3((uint32_t)(s_end - s_begin)), dim3(64), 0, stream, j, s_begin);
+	// the replay inside the plan (fixed-capacity mode) re-encodes blocks and needs the encoder's LDS
+	const size_t lds = j.fixed_capacity ? stenos_k_encode_lds_bytes(j.T) : 0;
+	if (lds) {
+		hipError_t e = hipFuncSetAttribute((const void*)plan_superblocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess)
+			return e;
+	}
+	hipLaunchKernelGGL(plan_superblocks, dim3((uint32_t)(s_end - s_begin)), dim3(64), lds, stream, j, s_begin);
 	return hipGetLastError();
 }
 

@@ -50,6 +50,12 @@ struct FrameJob {
 	uint32_t tiny_last;    // the last superblock is shorter than 128 bytes: finished by the host (zstd)
 	uint32_t override_code; // set by the host for the tiny last superblock before pack
 	uint32_t check_total;   // pack: compare *total with dst_size first (not needed where the plan proved that everything fits)
+	// levels >= 2 / bytesoftype 1 (stenos.cpp:546-547): every superblock is block-compressed into a buffer of exactly
+	// its own size, so the capacity rules need no prefix sum and are replayed inside plan_superblock; superblocks
+	// whose block stream fails or exceeds the input get code 0 / csize 0 (the host then takes the zstd strategies),
+	// and qprod[s] receives the bytes produced when the reference checks its target ratio (block_compress.h:1267)
+	uint32_t fixed_capacity;
+	uint32_t* qprod;
 };
 
 WV_HD uint32_t superblock_bytes(const FrameJob& j, uint64_t s)
@@ -74,7 +80,9 @@ WV_FN U32 block_requirement(const U32& a, const U32& info, const Pred& is_tail, 
 	return sel(!is_tail & lz, lzreq, a + need);
 }
 
-WV_FN void plan_superblock(const FrameJob& j, uint64_t s)
+WV_FN bool replay_superblock(Lds lds, const Layout& L, const FrameJob& j, uint64_t s, uint64_t C, uint32_t* payload);
+
+WV_FN void plan_superblock(Lds lds, const Layout& L, const FrameJob& j, uint64_t s)
 {
 	const U32 lane = lane_id();
 	const uint64_t first = s * j.bps;
@@ -106,6 +114,34 @@ WV_FN void plan_superblock(const FrameJob& j, uint64_t s)
 		code = 6;
 		csize = sbytes;
 		need = 0;
+	}
+	if (j.fixed_capacity) {
+		if (code == 1 && need > sbytes) { // capacity = the superblock's own size: exact replay right here
+			uint32_t payload = 0;
+			if (replay_superblock(lds, L, j, s, sbytes, &payload) && payload <= sbytes)
+				csize = payload;
+			else
+				code = 6;
+		}
+		if (code != 1) {
+			code = 0;
+			csize = 0;
+		}
+		// bytes produced once 1/16 of the input is consumed (full blocks only)
+		const uint32_t bs = 256 * j.T;
+		const uint32_t nfullb = count - (has_tail ? 1u : 0u);
+		uint32_t q = 0;
+		if (code == 1 && nfullb) {
+			uint32_t bq = (sbytes / 16 + bs - 1) / bs; // smallest b with b*bs >= sbytes/16, i.e. block index bq-1
+			bq = bq == 0 ? 0 : bq - 1;
+			if (bq < nfullb)
+				q = gload_uniform(j.boff + first + bq) + gload_uniform(j.bsize + first + bq);
+		}
+		gstore_uniform(j.qprod + s, q);
+		gst8(j.sb_code + s, lane, U32(code), lane == U32(0u));
+		gst32((uint8_t*)(j.sb_csize + s), U32(0u), U32(csize), lane == U32(0u));
+		gst32((uint8_t*)(j.sb_need + s), U32(0u), U32(0u), lane == U32(0u));
+		return;
 	}
 	// lower bound of this superblock's capacity: every earlier superblock stored as a copy
 	const uint64_t worst_off = (uint64_t)j.header_bytes + s * ((uint64_t)j.sb_bytes + 4) + 4;
@@ -232,6 +268,8 @@ WV_FN void pack_superblock(Lds lds, const FrameJob& j, uint64_t s, uint32_t w)
 	}
 	if (w == 0) // superblock header [code][csize:3 LE] (stenos.cpp:613-615)
 		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
+	if (code == 0) // levels >= 2: no block stream for this superblock (the host uses a zstd strategy)
+		return;
 	uint8_t* pay = base + 4;
 	// this wave's share of the payload, cut at destination dword boundaries
 	const uint32_t mis = (uint32_t)((uintptr_t)pay & 3u);

@@ -149,7 +149,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 			binfo[b] = r.info;
 		}
 	for (uint64_t s = 0; s < j.nsb; ++s) // plan_superblocks
-		plan_superblock(j, s);
+		plan_superblock(lds, L, j, s);
 	{ // scan_superblocks
 		uint64_t off = j.header_bytes;
 		for (uint64_t s = 0; s < j.nsb; ++s) {

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Hashes of frames the UNMODIFIED reference (oracle/_ref/libstenos_ref_det.so, linked against the image's zstd
+1.4.9) produces at levels 2..9 and for bytesoftype 1: pins the oracle's strategy layer (LZ4-dry estimator, zstd
+orchestration) on machines where the reference cannot be built.  Run: python tests/golden/make_levels_manifest.py"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+from _libs import has_error, load_ref, ref_compress  # noqa: E402
+from stenos_amd.datagen import generate  # noqa: E402
+
+CASES = []
+for level in (2, 3, 4, 5, 7, 9):
+    for T in (1, 2, 3, 4, 8, 12):
+        for kind in ("rand", "same", "sorted", "walk", "dict16", "runs", "burst", "ramp"):
+            for n in (100, 3000, 131072 // T + 77, 400000 // T):
+                CASES.append((kind, T, n, level))
+for level in (1, 2, 3, 6):
+    for n in (50, 5000, 300000):
+        CASES.append(("smooth8", 1, n, level))
+
+
+def main():
+    ref = load_ref(det=True)
+    if ref is None:
+        raise SystemExit("oracle/_ref/libstenos_ref_det.so missing")
+    out = []
+    for kind, T, n, level in CASES:
+        data = generate(kind, T, n, 42)
+        r, frame = ref_compress(ref, data, T, level)
+        assert not has_error(r)
+        out.append({"kind": kind, "T": T, "n": n, "level": level, "size": int(r), "sha256": hashlib.sha256(frame.tobytes()).hexdigest()})
+    with open(os.path.join(HERE, "levels_manifest.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_levels_manifest.py", "zstd": "1.4.9", "cases": out}, f, indent=0)
+    print(len(out), "cases")
+
+
+if __name__ == "__main__":
+    main()

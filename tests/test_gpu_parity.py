@@ -195,12 +195,13 @@ def test_unsupported_requests_fail_loudly(lib):
     c = lib.stenos_make_context()
     data = generate("walk", 4, 5000, 1)
     out = np.zeros(lib.stenos_bound(data.nbytes), dtype=np.uint8)
-    lib.stenos_set_level(c, 3)  # levels >= 2: next round (needs lz4-dry + zstd orchestration)
+    lib.stenos_set_max_nanoseconds(c, 1000)  # time-limited mode: wall-clock dependent output, not built
     assert has_error(lib.stenos_compress_generic(c, np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes))
-    lib.stenos_set_level(c, 1)
-    assert has_error(lib.stenos_compress_generic(c, np_ptr(data), 1, data.nbytes, np_ptr(out), out.nbytes))  # bytesoftype 1
-    lib.stenos_set_max_nanoseconds(c, 1000)
-    assert has_error(lib.stenos_compress_generic(c, np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes))
+    lib.stenos_set_max_nanoseconds(c, 0)
+    wide = generate("rand", 65, 3000, 1)  # bytesoftype > 64 at level >= 1: block does not fit the per-wave LDS budget
+    assert has_error(lib.stenos_compress_generic(c, np_ptr(wide), 65, wide.nbytes, np_ptr(np.zeros(lib.stenos_bound(wide.nbytes), dtype=np.uint8)),
+                                                 lib.stenos_bound(wide.nbytes)))
+    assert not out.any()
     lib.stenos_destroy_context(c)
 
 
