@@ -121,7 +121,7 @@ __global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t siz
 }
 
 template <uint32_t TT>
-__global__ __launch_bounds__(64) void decode_superblocks(DecodeArgs a)
+__global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 {
 	const uint32_t T = TT ? TT : a.T;
 	const uint64_t s = blockIdx.x;

@@ -179,10 +179,29 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 		uint32_t a = consumed + mis; // offset from abase
 		if (a >= wstart && a + need <= wstart + wfill)
 			return;
-		wstart = a & ~15u;
-		uint32_t endoff = csize + mis;
-		wfill = endoff - wstart < wcap ? endoff - wstart : wcap;
-		copy_g2l(lds, L.win, abase + wstart, wfill);
+		const uint32_t nstart = a & ~15u;
+		const uint32_t endoff = csize + mis;
+		const uint32_t nfill = endoff - nstart < wcap ? endoff - nstart : wcap;
+		uint32_t keep = 0;
+		if (wfill && nstart >= wstart && nstart < wstart + wfill && ((wstart + wfill) & 15u) == 0) {
+			// the bytes already in the window that are still needed slide to its start (LDS to LDS, ascending
+			// 1 KiB chunks: a chunk is read completely before it is written and never overlaps a later source),
+			// so every compressed byte is fetched from HBM once
+			keep = wstart + wfill - nstart;
+			const uint32_t d = nstart - wstart;
+			for (uint32_t o = 0; o < keep; o += 1024) {
+				U32 off = U32(o) + lane * 16u;
+				Pred p = off < U32(keep);
+				U128 v = lds_ld128(lds, U32(L.win + d) + sel(p, off, U32(0u)));
+				wave_sync();
+				lds_st128(lds, U32(L.win) + off, v, p);
+				wave_sync();
+			}
+		}
+		wstart = nstart;
+		wfill = nfill;
+		if (nfill > keep)
+			copy_g2l(lds, L.win + keep, abase + wstart + keep, nfill - keep);
 		wave_sync();
 	};
 
