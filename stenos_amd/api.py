@@ -39,6 +39,13 @@ def build_library() -> str:
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    # PyTorch-ROCm ships its own libamdhip64 and asks for it under a name the loader does not match with an
+    # already loaded /opt/rocm copy; two HIP runtimes in one process cannot both open the GPU.  Loading torch
+    # first makes libstenos.so resolve to the copy torch uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     sz, vp = c_size_t, c_void_p
     sigs = {

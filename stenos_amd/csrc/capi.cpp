@@ -15,7 +15,12 @@
 #include <string.h>
 #include <time.h>
 
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <memory>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/stenos_hip.h"
@@ -93,6 +98,61 @@ struct DevBuf {
 	}
 };
 
+// Host staging of the strategy layer (levels >= 2): page-locked so the transfers run at link speed; plain malloc
+// when the pinned allocation fails.  Kept by the context between calls.
+struct HostBuf {
+	uint8_t* p = nullptr;
+	size_t cap = 0;
+	bool pinned = false;
+	bool ensure(size_t n)
+	{
+		if (n <= cap)
+			return true;
+		release();
+		const size_t want = (n + (n >> 3) + 4095) & ~(size_t)4095;
+		void* q = nullptr;
+		if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess)
+			pinned = true;
+		else {
+			(void)hipGetLastError();
+			q = malloc(want);
+			pinned = false;
+		}
+		if (!q)
+			return false;
+		p = (uint8_t*)q;
+		cap = want;
+		return true;
+	}
+	void release()
+	{
+		if (p) {
+			if (pinned)
+				(void)hipHostFree(p);
+			else
+				free(p);
+		}
+		p = nullptr;
+		cap = 0;
+	}
+	uint8_t* data() const { return p; }
+};
+
+// STENOS_HOST_TRACE=1: wall-clock of the host phases of the strategy layer on stderr (diagnostics)
+struct PhaseTrace {
+	bool on;
+	std::chrono::steady_clock::time_point t;
+	PhaseTrace() : on(getenv("STENOS_HOST_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+	void mark(const char* what)
+	{
+		if (!on)
+			return;
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "[stenos] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+		t = n;
+	}
+};
+
 inline void put_le(uint8_t* p, uint64_t v, int n)
 {
 	for (int i = 0; i < n; ++i)
@@ -130,6 +190,7 @@ struct stenos_context_s {
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [24,32) scan carry, [64,320) override payload
+	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage; // host staging of the strategy layer
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
 	hipStream_t job_stream = nullptr;
@@ -168,6 +229,9 @@ struct stenos_context_s {
 	{
 		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1 };
 		for (DevBuf* b : all)
+			b->release();
+		HostBuf* host[] = { &h_in, &h_out, &h_blocks, &h_shuf, &h_mid0, &h_mid1, &h_stage };
+		for (HostBuf* b : host)
 			b->release();
 		if (h_total)
 			(void)hipHostFree(h_total);
@@ -434,6 +498,35 @@ size_t host_copy_superblock(const uint8_t* src, size_t bytes, uint8_t* dst, size
 	return bytes + 4;
 }
 
+// Host side worker threads for the zstd stages of levels >= 2 (one superblock per task).
+unsigned host_threads()
+{
+	unsigned n = std::thread::hardware_concurrency();
+	if (const char* e = getenv("STENOS_HOST_THREADS"))
+		if (atoi(e) > 0)
+			n = (unsigned)atoi(e);
+	return n > 64 ? 64 : n < 1 ? 1 : n;
+}
+
+void parallel_for(uint64_t cnt, const std::function<void(uint64_t)>& fn)
+{
+	std::atomic<uint64_t> next(0);
+	auto worker = [&]() {
+		for (uint64_t k; (k = next.fetch_add(1)) < cnt;)
+			fn(k);
+	};
+	const unsigned nthreads = host_threads();
+	const unsigned nt = (unsigned)(cnt < nthreads ? cnt : nthreads);
+	if (nt <= 1)
+		return worker();
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < nt; ++t)
+		pool.emplace_back(worker);
+	worker();
+	for (auto& t : pool)
+		t.join();
+}
+
 // Levels >= 2 and bytesoftype 1: the strategy layer of compress_generic_superblock (stenos.cpp:451-604, 617-678).
 // The GPU encodes every superblock with the block codec (capacity = the superblock's own size, as the reference's
 // scratch buffer), shuffles the input and prepares the plane middles for the LZ4-dry estimates; the host runs
@@ -505,12 +598,17 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	    hipMemcpyAsync(sboff.data(), j.sb_off, (f.nsb + 1) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 	    hipStreamSynchronize(stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	std::vector<uint8_t> blocks((size_t)sboff[f.nsb]);
-	if (!blocks.empty() && hipMemcpy(blocks.data(), j.dst, blocks.size(), hipMemcpyDeviceToHost) != hipSuccess)
+	PhaseTrace trace;
+	HostBuf& blocks = ctx->h_blocks;
+	const size_t blocks_size = (size_t)sboff[f.nsb];
+	if (!blocks.ensure(blocks_size + 64))
+		return STENOS_ERROR_ALLOC;
+	if (blocks_size && hipMemcpy(blocks.data(), j.dst, blocks_size, hipMemcpyDeviceToHost) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	trace.mark("block streams to host");
 	// transposed views for the estimator and the transposed zstd strategies (levels > 2 only, stenos.cpp:515-537)
 	const bool transposed = T > 1 && level > 2;
-	std::vector<uint8_t> shuf, mid0, mid1, delta_full;
+	HostBuf &shuf = ctx->h_shuf, &mid0 = ctx->h_mid0, &mid1 = ctx->h_mid1;
 	if (transposed) {
 		if (!ctx->shuf.ensure(bytes + 64) || !ctx->mid0.ensure(bytes + 64) || !ctx->mid1.ensure(bytes + 64))
 			return STENOS_ERROR_ALLOC;
@@ -518,13 +616,13 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		    stenos_k_launch_delta_middles(ctx->shuf.as<uint8_t>(), ctx->mid0.as<uint8_t>(), (uint32_t)T, f.sb, bytes, (uint32_t)level, false, stream) != hipSuccess ||
 		    stenos_k_launch_delta_middles(ctx->shuf.as<uint8_t>(), ctx->mid1.as<uint8_t>(), (uint32_t)T, f.sb, bytes, (uint32_t)level, true, stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
-		shuf.resize(bytes);
-		mid0.resize(bytes);
-		mid1.resize(bytes);
+		if (!shuf.ensure(bytes + 64) || !mid0.ensure(bytes + 64) || !mid1.ensure(bytes + 64))
+			return STENOS_ERROR_ALLOC;
 		if (hipMemcpy(shuf.data(), ctx->shuf.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
 		    hipMemcpy(mid0.data(), ctx->mid0.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
 		    hipMemcpy(mid1.data(), ctx->mid1.p, bytes, hipMemcpyDeviceToHost) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
+		trace.mark("transposed views to host");
 	}
 
 	int zstd_level = level; // stenos.cpp:441-460
@@ -535,108 +633,151 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	}
 	const int zl = zstd_level_of(zstd_level);
 	const size_t bs = 256 * T;
-	size_t off = f.header;
-	for (uint64_t s = 0; s < f.nsb; ++s) {
-		if (dst_size < off + 4) // stenos.cpp:427-429
-			return STENOS_ERROR_DST_OVERFLOW;
-		const size_t room = dst_size - off;
+	// What a superblock becomes is decided first (it does not depend on the room left in the destination):
+	//   0 = tiny input, plain zstd level 1 (stenos.cpp:435-437)      1 = block codec + zstd (code 5, or 1)
+	//   2/3/4 = zstd over the raw / transposed / transposed+delta bytes (stenos.cpp:548-558)
+	auto decide = [&](uint64_t s) -> int {
 		const uint8_t* src = h_src + s * f.sb;
 		const size_t sbytes = (size_t)((bytes - s * f.sb) < f.sb ? (bytes - s * f.sb) : f.sb);
-		uint8_t* out = h_dst + off;
-		size_t r;
-		if (sbytes < 128) { // small input: direct zstd with zstd level 1 (stenos.cpp:435-437)
-			r = zstd().compress(out + 4, room - 4, src, sbytes, 1);
-			if (zstd().is_error(r) || r > sbytes)
-				r = host_copy_superblock(src, sbytes, out, room);
-			else {
-				out[0] = 2;
-				put_le(out + 1, r, 3);
-				r += 4;
+		if (sbytes < 128)
+			return 0;
+		double lz_ratio = 1.1, lz_tr = 0, lz_trd = 0;
+		if (sbytes >= bs)
+			lz_ratio = (double)(sbytes / 16) / (double)strategy::lz4_dry_size(src, sbytes / 16, 10 - level);
+		if (T > 1) {
+			if (transposed && sbytes >= bs) {
+				const size_t step = strategy::middle_step(T, sbytes, level);
+				lz_tr = strategy::transposed_ratio(mid0.data() + s * f.sb, T, step, level);
+				if (lz_tr > lz_ratio)
+					lz_ratio = lz_tr;
+				lz_trd = strategy::transposed_ratio(mid1.data() + s * f.sb, T, step, level) * 1.1;
+				if (lz_trd > lz_ratio)
+					lz_ratio = lz_trd;
+				const double factor = 1. + level / 12.;
+				lz_tr *= factor;
+				lz_trd *= factor;
+				lz_ratio *= factor;
 			}
 		}
-		else {
-			double lz_ratio = 1.1, lz_tr = 0, lz_trd = 0;
-			if (sbytes >= bs)
-				lz_ratio = (double)(sbytes / 16) / (double)strategy::lz4_dry_size(src, sbytes / 16, 10 - level);
-			if (T > 1) {
-				if (transposed && sbytes >= bs) {
-					const size_t step = strategy::middle_step(T, sbytes, level);
-					lz_tr = strategy::transposed_ratio(mid0.data() + s * f.sb, T, step, level);
-					if (lz_tr > lz_ratio)
-						lz_ratio = lz_tr;
-					lz_trd = strategy::transposed_ratio(mid1.data() + s * f.sb, T, step, level) * 1.1;
-					if (lz_trd > lz_ratio)
-						lz_ratio = lz_trd;
-					const double factor = 1. + level / 12.;
-					lz_tr *= factor;
-					lz_trd *= factor;
-					lz_ratio *= factor;
+		else
+			lz_ratio *= 1. + level / 12.;
+		// block codec result of the GPU; the reference gives up when, after 1/16 of the input, the running
+		// ratio is below the estimate (block_compress.h:1266-1274)
+		bool ok = code[s] == 1;
+		if (ok && qprod[s]) {
+			size_t bq = (sbytes / 16 + bs - 1) / bs;
+			bq = bq == 0 ? 0 : bq - 1;
+			const double ratio = (double)((bq + 1) * bs) / (double)qprod[s];
+			if (ratio < lz_ratio)
+				ok = false;
+		}
+		if (ok)
+			return 1;
+		int c = 2; // stenos.cpp:548-558
+		if (lz_ratio > 1.40) {
+			if (lz_ratio == lz_tr)
+				c = 3;
+			else if (lz_ratio == lz_trd)
+				c = 4;
+		}
+		return c;
+	};
+
+	// One superblock -> [code][csize:3][payload] at `out` with `room` bytes of capacity (what the reference
+	// hands to its strategies, stenos.cpp:895).  `delta_src`: the GPU's byte delta of the transposed
+	// superblock for choice 4.  Returns the bytes written or an error code.
+	auto emit = [&](uint64_t s, int choice, const uint8_t* delta_src, uint8_t* out, size_t room) -> size_t {
+		const uint8_t* src = h_src + s * f.sb;
+		const size_t sbytes = (size_t)((bytes - s * f.sb) < f.sb ? (bytes - s * f.sb) : f.sb);
+		size_t r;
+		if (choice == 1) {
+			const uint8_t* payload = blocks.data() + sboff[s] + 4;
+			const size_t cblock = csize[s];
+			r = zstd().compress(out + 4, room - 4, payload, cblock, zl); // stenos.cpp:583
+			if (zstd().is_error(r) || r > cblock) {                     // NO_ZSTD (:585-596)
+				if (room < 4 + cblock)
+					return (size_t)STENOS_ERROR_DST_OVERFLOW;
+				out[0] = 1;
+				put_le(out + 1, cblock, 3);
+				memcpy(out + 4, payload, cblock);
+				return cblock + 4;
+			}
+			out[0] = 5;
+			put_le(out + 1, r, 3);
+			return r + 4;
+		}
+		const uint8_t* zsrc = choice == 3 ? shuf.data() + s * f.sb : choice == 4 ? delta_src : src;
+		r = zstd().compress(out + 4, room - 4, zsrc, sbytes, choice == 0 ? 1 : zl);
+		if (zstd().is_error(r) || r > sbytes)
+			return host_copy_superblock(src, sbytes, out, room);
+		out[0] = (uint8_t)(choice == 0 ? 2 : choice);
+		put_le(out + 1, r, 3);
+		return r + 4;
+	};
+
+	// zstd's result depends on the capacity only below ZSTD_compressBound of its input, so the superblocks of a
+	// batch are compressed in parallel into roomy scratch buffers and then laid out in order; a superblock that
+	// meets less room than that in the caller's buffer (the end of a tight buffer) is redone with the exact
+	// capacity, as the reference's serial loop would have seen it.
+	const size_t ample = 4 + f.sb + f.sb / 128 + 1024;
+	uint64_t batch = ((size_t)256 << 20) / f.sb;
+	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
+	std::vector<int> choice;
+	std::unique_ptr<uint8_t[]> scratch(new (std::nothrow) uint8_t[(size_t)(batch < f.nsb ? batch : f.nsb) * ample]);
+	if (!scratch)
+		return STENOS_ERROR_ALLOC;
+	std::vector<size_t> sizes;
+	std::vector<uint64_t> dslot; // position of a choice-4 superblock in the batch's delta buffer
+	std::vector<uint8_t> deltas;
+	size_t off = f.header;
+	for (uint64_t s0 = 0; s0 < f.nsb; s0 += batch) {
+		const uint64_t cnt = (s0 + batch < f.nsb ? s0 + batch : f.nsb) - s0;
+		choice.assign(cnt, 0);
+		parallel_for(cnt, [&](uint64_t k) { choice[k] = decide(s0 + k); });
+		trace.mark("estimates");
+		// byte delta of the whole transposed superblock on the GPU for the choice-4 ones (stenos.cpp:646)
+		dslot.assign(cnt, 0);
+		uint64_t nd = 0;
+		for (uint64_t k = 0; k < cnt; ++k)
+			if (choice[k] == 4)
+				dslot[k] = nd++;
+		if (nd) {
+			if (!ctx->tmp2.ensure(nd * f.sb + 64))
+				return STENOS_ERROR_ALLOC;
+			deltas.resize(nd * f.sb);
+			for (uint64_t k = 0; k < cnt; ++k)
+				if (choice[k] == 4) {
+					const uint64_t s = s0 + k;
+					const size_t sbytes = (size_t)((bytes - s * f.sb) < f.sb ? (bytes - s * f.sb) : f.sb);
+					if (stenos_k_launch_delta(ctx->shuf.as<uint8_t>() + s * f.sb, ctx->tmp2.as<uint8_t>() + dslot[k] * f.sb, sbytes, false, stream) !=
+					    hipSuccess)
+						return STENOS_ERROR_UNDEFINED;
 				}
+			if (hipMemcpyAsync(deltas.data(), ctx->tmp2.p, nd * f.sb, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			    hipStreamSynchronize(stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+		}
+		sizes.assign(cnt, 0);
+		parallel_for(cnt, [&](uint64_t k) {
+			sizes[k] = emit(s0 + k, choice[k], deltas.data() + dslot[k] * f.sb, scratch.get() + k * ample, ample);
+		});
+		trace.mark("zstd");
+		for (uint64_t k = 0; k < cnt; ++k) {
+			if (dst_size < off + 4) // stenos.cpp:427-429
+				return STENOS_ERROR_DST_OVERFLOW;
+			const size_t room = dst_size - off;
+			size_t r = sizes[k];
+			if (room >= ample) {
+				if (!is_err(r))
+					memcpy(h_dst + off, scratch.get() + k * ample, r);
 			}
 			else
-				lz_ratio *= 1. + level / 12.;
-			// block codec result of the GPU; the reference gives up when, after 1/16 of the input, the running
-			// ratio is below the estimate (block_compress.h:1266-1274)
-			bool ok = code[s] == 1;
-			if (ok && qprod[s]) {
-				size_t bq = (sbytes / 16 + bs - 1) / bs;
-				bq = bq == 0 ? 0 : bq - 1;
-				const double ratio = (double)((bq + 1) * bs) / (double)qprod[s];
-				if (ratio < lz_ratio)
-					ok = false;
-			}
-			if (ok) {
-				const uint8_t* payload = blocks.data() + sboff[s] + 4;
-				const size_t cblock = csize[s];
-				r = zstd().compress(out + 4, room - 4, payload, cblock, zl); // stenos.cpp:583
-				if (zstd().is_error(r) || r > cblock) {                     // NO_ZSTD (:585-596)
-					if (room < 4 + cblock)
-						return STENOS_ERROR_DST_OVERFLOW;
-					out[0] = 1;
-					put_le(out + 1, cblock, 3);
-					memcpy(out + 4, payload, cblock);
-					r = cblock + 4;
-				}
-				else {
-					out[0] = 5;
-					put_le(out + 1, r, 3);
-					r += 4;
-				}
-			}
-			else {
-				int c = 2; // stenos.cpp:548-558
-				if (lz_ratio > 1.40) {
-					if (lz_ratio == lz_tr)
-						c = 3;
-					else if (lz_ratio == lz_trd)
-						c = 4;
-				}
-				const uint8_t* zsrc = src;
-				if (c == 3)
-					zsrc = shuf.data() + s * f.sb;
-				else if (c == 4) { // byte delta of the whole transposed superblock on the GPU (stenos.cpp:646)
-					if (!ctx->tmp2.ensure(sbytes + 64))
-						return STENOS_ERROR_ALLOC;
-					delta_full.resize(sbytes);
-					if (stenos_k_launch_delta(ctx->shuf.as<uint8_t>() + s * f.sb, ctx->tmp2.as<uint8_t>(), sbytes, false, stream) != hipSuccess ||
-					    hipMemcpyAsync(delta_full.data(), ctx->tmp2.p, sbytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-					    hipStreamSynchronize(stream) != hipSuccess)
-						return STENOS_ERROR_UNDEFINED;
-					zsrc = delta_full.data();
-				}
-				r = zstd().compress(out + 4, room - 4, zsrc, sbytes, zl);
-				if (zstd().is_error(r) || r > sbytes)
-					r = host_copy_superblock(src, sbytes, out, room);
-				else {
-					out[0] = (uint8_t)c;
-					put_le(out + 1, r, 3);
-					r += 4;
-				}
-			}
+				r = emit(s0 + k, choice[k], deltas.data() + dslot[k] * f.sb, h_dst + off, room);
+			if (is_err(r))
+				return r;
+			off += r;
 		}
-		if (is_err(r))
-			return r;
-		off += r;
+		trace.mark("layout");
 	}
 	return off;
 }
@@ -660,7 +801,9 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 		// the strategy layer needs the input on the host (estimator, zstd): fetch it, assemble the frame there
 		const size_t roomy = stenos_bound(bytes) + f.sb / 128 + 4096; // beyond ZSTD_compressBound of a superblock the capacity no longer matters
 		const size_t cap = dst_size < roomy ? dst_size : roomy;
-		std::vector<uint8_t> h_src(bytes), h_out(cap);
+		HostBuf &h_src = ctx->h_in, &h_out = ctx->h_out;
+		if (!h_src.ensure(bytes + 64) || !h_out.ensure(cap + 64))
+			return STENOS_ERROR_ALLOC;
 		if (hipMemcpyAsync(h_src.data(), d_src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 		size_t r = compress_strategy(ctx, h_src.data(), (const uint8_t*)d_src, T, bytes, h_out.data(), cap, level, f, stream);
@@ -744,93 +887,131 @@ size_t parse_frame(const uint8_t* h, size_t have, size_t T, size_t dst_size, Fra
 size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const uint8_t* h_frame, size_t size, size_t T, const uint64_t* h_index,
 			 const FrameInfo& fi, uint8_t* d_dst, hipStream_t stream)
 {
-	std::vector<uint8_t> comp, raw;
+	PhaseTrace trace;
+	if (!h_frame) {
+		HostBuf& frame_copy = ctx->h_in;
+		if (!frame_copy.ensure(size + 64))
+			return STENOS_ERROR_ALLOC;
+		if (hipMemcpyAsync(frame_copy.data(), d_frame, size, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		h_frame = frame_copy.data();
+	}
+	struct Item {
+		uint64_t s;
+		uint32_t code;
+		size_t csize, dsize, r;
+	};
+	std::vector<Item> items;
+	bool any5 = false;
 	for (uint64_t s = 0; s < fi.nsb; ++s) {
-		uint8_t hd[4];
 		if (h_index[s] + 4 > size)
 			return STENOS_ERROR_SRC_OVERFLOW;
-		if (h_frame)
-			memcpy(hd, h_frame + h_index[s], 4);
-		else if (hipMemcpyAsync(hd, d_frame + h_index[s], 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
+		const uint8_t* hd = h_frame + h_index[s];
 		const unsigned code = hd[0];
 		if (code == 1 || code == 6)
 			continue;
 		if (code < 2 || code > 5)
 			return STENOS_ERROR_INVALID_INPUT;
-		if (!zstd().ok)
-			return STENOS_ERROR_ZSTD_INTERNAL;
 		const size_t csize = (size_t)get_le(hd + 1, 3);
 		const uint64_t begin = s * (uint64_t)fi.sb;
 		const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
 		if (h_index[s] + 4 + csize > size)
 			return STENOS_ERROR_INVALID_INPUT;
-		const uint8_t* payload = nullptr;
-		if (h_frame)
-			payload = h_frame + h_index[s] + 4;
-		else {
-			comp.resize(csize);
-			if (hipMemcpyAsync(comp.data(), d_frame + h_index[s] + 4, csize, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-			    hipStreamSynchronize(stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
-			payload = comp.data();
+		any5 |= code == 5;
+		items.push_back({ s, code, csize, dsize, 0 });
+	}
+	if (items.empty())
+		return 0;
+	if (!zstd().ok)
+		return STENOS_ERROR_ZSTD_INTERNAL;
+	if (any5 && T > kMaxT)
+		return STENOS_ERROR_INVALID_PARAMETER;
+
+	// The superblocks are inflated by the worker threads into one staging buffer per batch (slot k: 12 spare bytes,
+	// a [1][size:3] header for code 5, the bytes at +16), moved to the device in one copy and finished there.
+	const size_t slot = (((size_t)fi.sb + 64 + 15) & ~(size_t)15) + 16;
+	uint64_t batch = ((size_t)256 << 20) / slot;
+	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
+	if (batch > items.size())
+		batch = items.size();
+	if (!ctx->tmp1.ensure(batch * slot + 64) || !ctx->tmp2.ensure(batch * slot + 64) || !ctx->bsize.ensure(batch * 4 + 64) ||
+	    !ctx->binfo.ensure(batch * 8 + 64) || !ctx->misc.ensure(4096))
+		return STENOS_ERROR_ALLOC;
+	uint8_t* t1 = ctx->tmp1.as<uint8_t>();
+	uint8_t* t2 = ctx->tmp2.as<uint8_t>();
+	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
+	HostBuf& stage = ctx->h_stage;
+	if (!stage.ensure(batch * slot + 64))
+		return STENOS_ERROR_ALLOC;
+	std::vector<uint32_t> ids;
+	std::vector<uint64_t> idx;
+	for (size_t i0 = 0; i0 < items.size(); i0 += batch) {
+		const size_t cnt = items.size() - i0 < batch ? items.size() - i0 : (size_t)batch;
+		parallel_for(cnt, [&](uint64_t k) {
+			Item& it = items[i0 + k];
+			// code 5: zstd over the block stream, at most the superblock size (stenos.cpp:732)
+			const size_t cap = it.code == 5 ? (size_t)fi.sb + 64 : it.dsize;
+			it.r = zstd().decompress(stage.data() + k * slot + 16, cap, h_frame + h_index[it.s] + 4, it.csize);
+		});
+		trace.mark("zstd inflate");
+		ids.clear();
+		idx.clear();
+		for (size_t k = 0; k < cnt; ++k) {
+			const Item& it = items[i0 + k];
+			if (zstd().is_error(it.r) || (it.code != 5 && it.code != 2 && it.r != it.dsize)) // stenos.cpp:696-698, 706-708, 718-720
+				return STENOS_ERROR_INVALID_INPUT;
+			if (it.code == 5) { // -> one BLOCK superblock for the block decoder (stenos.cpp:726-740)
+				uint8_t* h4 = stage.data() + k * slot + 12;
+				h4[0] = 1;
+				put_le(h4 + 1, it.r, 3);
+				ids.push_back((uint32_t)it.s);
+				idx.push_back(k * slot + 12);
+			}
 		}
-		const size_t cap = code == 5 ? fi.sb + 64 : dsize; // code 5: zstd over the block stream, at most the superblock size (stenos.cpp:732)
-		raw.resize(cap);
-		size_t r = zstd().decompress(raw.data(), cap, payload, csize);
-		if (zstd().is_error(r) || (code != 5 && code != 2 && r != dsize)) // stenos.cpp:696-698, 706-708, 718-720
-			return STENOS_ERROR_INVALID_INPUT;
-		if (code == 2) { // plain zstd
-			if (hipMemcpyAsync(d_dst + begin, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
-			continue;
-		}
-		if (!ctx->tmp1.ensure(cap + 64) || !ctx->tmp2.ensure(cap + 64))
-			return STENOS_ERROR_ALLOC;
-		uint8_t* t1 = ctx->tmp1.as<uint8_t>();
-		uint8_t* t2 = ctx->tmp2.as<uint8_t>();
-		if (code == 3) { // zstd on the transposed superblock (stenos.cpp:700-710)
-			if (hipMemcpyAsync(t1, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess ||
-			    stenos_k_launch_shuffle(t1, d_dst + begin, (uint32_t)T, dsize, true, stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
-		}
-		else if (code == 4) { // transposed + byte delta (stenos.cpp:711-725)
-			if (hipMemcpyAsync(t1, raw.data(), dsize, hipMemcpyHostToDevice, stream) != hipSuccess ||
-			    stenos_k_launch_delta(t1, t2, dsize, true, stream) != hipSuccess ||
-			    stenos_k_launch_shuffle(t2, d_dst + begin, (uint32_t)T, dsize, true, stream) != hipSuccess)
+		if (hipMemcpyAsync(t1, stage.data(), cnt * slot, hipMemcpyHostToDevice, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		for (size_t k = 0; k < cnt; ++k) {
+			const Item& it = items[i0 + k];
+			uint8_t* out = d_dst + it.s * (uint64_t)fi.sb;
+			const uint8_t* in = t1 + k * slot + 16;
+			hipError_t e = hipSuccess;
+			if (it.code == 2) // plain zstd
+				e = hipMemcpyAsync(out, in, it.dsize, hipMemcpyDeviceToDevice, stream);
+			else if (it.code == 3) // zstd on the transposed superblock (stenos.cpp:700-710)
+				e = stenos_k_launch_shuffle(in, out, (uint32_t)T, it.dsize, true, stream);
+			else if (it.code == 4) { // transposed + byte delta (stenos.cpp:711-725)
+				e = stenos_k_launch_delta(in, t2 + k * slot, it.dsize, true, stream);
+				if (e == hipSuccess)
+					e = stenos_k_launch_shuffle(t2 + k * slot, out, (uint32_t)T, it.dsize, true, stream);
+			}
+			if (e != hipSuccess)
 				return STENOS_ERROR_UNDEFINED;
 		}
-		else { // code 5: zstd over the block stream (stenos.cpp:726-740) -> one BLOCK superblock for the block decoder
-			if (T > kMaxT)
-				return STENOS_ERROR_INVALID_PARAMETER;
-			uint8_t h4[4] = { 1, (uint8_t)r, (uint8_t)(r >> 8), (uint8_t)(r >> 16) };
-			const uint64_t idx[2] = { 0, 4 + (uint64_t)r };
-			uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
-			uint64_t* d_idx = (uint64_t*)(ctx->misc.as<uint8_t>() + 32);
-			if (hipMemcpyAsync(t1, h4, 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
-			    hipMemcpyAsync(t1 + 4, raw.data(), r, hipMemcpyHostToDevice, stream) != hipSuccess ||
-			    hipMemcpyAsync(d_idx, idx, 16, hipMemcpyHostToDevice, stream) != hipSuccess || hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess)
+		uint32_t status = 0;
+		if (!ids.empty()) {
+			if (hipMemcpyAsync(ctx->bsize.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    hipMemcpyAsync(ctx->binfo.p, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess)
 				return STENOS_ERROR_UNDEFINED;
 			DecodeArgs a;
 			a.frame = t1;
-			a.size = 4 + r;
-			a.sb_off = d_idx;
-			a.dst = d_dst + begin;
-			a.total_bytes = dsize;
-			a.nsb = 1;
-			a.sb_bytes = (uint32_t)dsize;
+			a.size = cnt * slot;
+			a.sb_off = ctx->binfo.as<uint64_t>();
+			a.sb_ids = ctx->bsize.as<uint32_t>();
+			a.dst = d_dst;
+			a.total_bytes = fi.total;
+			a.nsb = ids.size();
+			a.sb_bytes = (uint32_t)fi.sb;
 			a.T = (uint32_t)T;
 			a.status = d_status;
-			uint32_t status = 0;
-			if (stenos_k_launch_decode(a, stream) != hipSuccess || hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-			    hipStreamSynchronize(stream) != hipSuccess)
+			if (stenos_k_launch_decode(a, stream) != hipSuccess || hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
 				return STENOS_ERROR_UNDEFINED;
-			if (status)
-				return STENOS_ERROR_INVALID_INPUT;
-			continue;
 		}
-		if (hipStreamSynchronize(stream) != hipSuccess) // raw is reused by the next superblock
+		if (hipStreamSynchronize(stream) != hipSuccess) // the staging buffers are reused by the next batch
 			return STENOS_ERROR_UNDEFINED;
+		if (status)
+			return STENOS_ERROR_INVALID_INPUT;
+		trace.mark("device finish");
 	}
 	return 0;
 }
@@ -1042,26 +1223,29 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	for (uint64_t s = 0; s < fi.nsb && !device_codes; ++s)
 		device_codes = in[index[s]] >= 3 && in[index[s]] <= 5;
 	if (!device_codes) { // copies and zstd-only superblocks: nothing for the GPU to do
-		for (uint64_t s = 0; s < fi.nsb; ++s) {
+		std::atomic<size_t> err(0);
+		parallel_for(fi.nsb, [&](uint64_t s) {
 			const uint64_t begin = s * (uint64_t)fi.sb;
 			const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
 			const unsigned code = in[index[s]];
 			const size_t csize = (size_t)get_le(in + index[s] + 1, 3);
 			if (code == 6) {
 				if (csize != dsize)
-					return STENOS_ERROR_INVALID_INPUT;
-				memcpy(out + begin, in + index[s] + 4, csize);
+					err = STENOS_ERROR_INVALID_INPUT;
+				else
+					memcpy(out + begin, in + index[s] + 4, csize);
 			}
 			else if (code == 2) {
 				if (!zstd().ok)
-					return STENOS_ERROR_ZSTD_INTERNAL;
-				size_t r = zstd().decompress(out + begin, dsize, in + index[s] + 4, csize);
-				if (zstd().is_error(r))
-					return STENOS_ERROR_INVALID_INPUT;
+					err = STENOS_ERROR_ZSTD_INTERNAL;
+				else if (zstd().is_error(zstd().decompress(out + begin, dsize, in + index[s] + 4, csize)))
+					err = STENOS_ERROR_INVALID_INPUT;
 			}
 			else
-				return STENOS_ERROR_INVALID_INPUT; // codes 3-5: levels >= 2, not handled by this build yet
-		}
+				err = STENOS_ERROR_INVALID_INPUT;
+		});
+		if (err)
+			return err;
 		return (size_t)fi.total;
 	}
 	if (!ctx->device_ready())

@@ -16,6 +16,7 @@ struct DecodeArgs {
 	const uint8_t* frame;
 	uint64_t size; // frame bytes
 	const uint64_t* sb_off;
+	const uint32_t* sb_ids = nullptr; // superblock numbers of the launch's entries; NULL: 0, 1, 2, ...
 	uint8_t* dst;
 	uint64_t total_bytes;
 	uint64_t nsb;

@@ -124,9 +124,9 @@ template <uint32_t TT>
 __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 {
 	const uint32_t T = TT ? TT : a.T;
-	const uint64_t s = blockIdx.x;
+	const uint64_t s = a.sb_ids ? a.sb_ids[blockIdx.x] : blockIdx.x;
 	const U32 lane = lane_id();
-	const uint64_t p = a.sb_off[s];
+	const uint64_t p = a.sb_off[blockIdx.x];
 	if (p + 4 > a.size) {
 		if (threadIdx.x == 0)
 			atomicOr(a.status, DECODE_STATUS_TRUNCATED);

@@ -122,3 +122,26 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and abs(d["compression_ratio"] - 2.52) < 0.01
+
+
+@pytest.mark.gpu
+def test_library_before_torch_in_fresh_process():
+    """libstenos.so loaded before torch must still share one HIP runtime with it."""
+    import subprocess
+    import sys
+
+    code = (
+        "from stenos_amd.api import Stenos\n"
+        "st = Stenos(level=1)\n"
+        "import torch\n"
+        "src = (torch.arange(1 << 20, dtype=torch.int32, device='cuda') & 0xFFF).view(torch.uint8)\n"
+        "dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device='cuda')\n"
+        "back = torch.empty_like(src)\n"
+        "c = st.compress(src, 4, dst)\n"
+        "st.decompress(dst, 4, c, back)\n"
+        "assert torch.equal(src, back)\n"
+        "print('ok', c)\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
