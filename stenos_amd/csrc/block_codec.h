@@ -28,7 +28,7 @@ constexpr uint32_t MAX_T = 64; // largest bytesoftype handled by the LDS-residen
 // Byte offsets of the regions of one wave's LDS scratch.
 struct Layout {
 	uint32_t in;      // raw block, element major: 256*T bytes (+8 slack)
-	uint32_t out;     // encoded image: out_capacity(T) bytes, zeroed by the codec
+	uint32_t out;     // encoded image: out_capacity(T) bytes, zeroed by the codec; the 16 bytes in front of it belong to RunStream
 	uint32_t rowinfo; // T*16 entries of 8 bytes
 	uint32_t plinfo;  // T entries of 4 bytes
 	uint32_t aux;     // 64 entries of 8 bytes (row statistics of the current plane group) / decoder scratch
@@ -49,6 +49,7 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	uint32_t o = 0;
 	L.in = o;
 	o += align16(256 * T + 16);
+	o += 16; // bytes of the previous block that wait for a full 16-byte group (superblock_codec.h, RunStream)
 	L.out = o;
 	o += out_capacity(T);
 	L.rowinfo = o;

@@ -187,6 +187,7 @@ struct stenos_context_s {
 	bool probed = false, usable = false;
 	DevBuf in, out;                                  // staging for the host-pointer ABI
 	DevBuf slots, bsize, binfo, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
+	DevBuf chain;                                    // fused path: ticket counter + one chained-scan word per superblock
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [24,32) scan carry, [64,320) override payload
@@ -227,7 +228,7 @@ struct stenos_context_s {
 	}
 	~stenos_context_s()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1 };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain };
 		for (DevBuf* b : all)
 			b->release();
 		HostBuf* host[] = { &h_in, &h_out, &h_blocks, &h_shuf, &h_mid0, &h_mid1, &h_stage };
@@ -369,11 +370,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	// last one or two) need no capacity replay and no overflow check; they are processed in chunks, the
 	// pack of a chunk overlapping the encoding of the next one on a second stream.  The remaining tail zone
 	// goes through plan / scan / resolve / pack in order.
-	const uint64_t need_max = (uint64_t)(f.bps + 1) * (256 * T + (T + 1) / 2) + 288 * T + 64;
-	const uint64_t fixed = header + 4 + need_max;
-	uint64_t s_tight = dst_size >= fixed ? (dst_size - fixed) / (f.sb + 4) + 1 : 0;
-	if (s_tight > f.nsb)
-		s_tight = f.nsb;
+	uint64_t s_tight = codec::safe_superblocks(dst_size, header, f.bps, (uint32_t)T, f.sb, f.nsb);
 	if (tiny_last && s_tight > f.nsb - 1)
 		s_tight = f.nsb - 1;
 	const uint64_t nblocks_all = f.nfull + (f.tail ? 1 : 0);
@@ -389,19 +386,39 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	    hipMemcpyAsync(d_carry, &carry0, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
 	    hipMemcpyAsync(j.total, &carry0, 8, hipMemcpyHostToDevice, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	if (s_tight > 0) {
+	// Safe superblocks that consist of full blocks go through the fused kernel (encode + chained offsets + store in
+	// one launch); STENOS_NO_FUSED=1 sends them through encode / plan / scan / pack like the rest.
+	uint64_t s_fused = 0;
+	if (level >= 1 && stenos_k_fused_supported((uint32_t)T) && !getenv("STENOS_NO_FUSED")) {
+		s_fused = f.nfull / f.bps < s_tight ? f.nfull / f.bps : s_tight;
+		if (s_fused) {
+			const size_t stage_bytes = stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused);
+			if (!ctx->slots.ensure(stage_bytes) || !ctx->chain.ensure((s_fused + 2) * 8))
+				return STENOS_ERROR_ALLOC;
+			j.slots = ctx->slots.as<uint8_t>();
+			uint64_t* desc = ctx->chain.as<uint64_t>() + 1; // word 0: ticket counter
+			ctx->mark(0, stream);
+			if (hipMemsetAsync(ctx->chain.p, 0, (s_fused + 2) * 8, stream) != hipSuccess ||
+			    stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			ctx->mark(1, stream);
+		}
+	}
+	if (s_tight > s_fused) {
 		// Measured on MI355X (8 GiB int32): overlapping the pack of chunk k with the encoding of chunk k+1 on a
 		// second stream gains nothing (748-802 GB/s against 725-764 GB/s for one chunk; chunks below 128 MiB are
-		// launch-bound), so by default the safe zone is one chunk.  STENOS_CHUNK_MIB enables the chunked form.
-		uint64_t csb = s_tight;
+		// launch-bound), so by default the zone is one chunk.  STENOS_CHUNK_MIB enables the chunked form.
+		uint64_t csb = s_tight - s_fused;
 		if (const char* e = getenv("STENOS_CHUNK_MIB"))
 			if (atoi(e) > 0)
 				csb = ((uint64_t)atoi(e) << 20) / f.sb;
 		if (csb == 0)
 			csb = 1;
-		const bool overlap = s_tight > csb && ctx->ensure_aux();
+		const bool overlap = s_tight - s_fused > csb && ctx->ensure_aux();
 		hipStream_t s2 = overlap ? ctx->aux_stream : stream;
-		for (uint64_t s0 = 0; s0 < s_tight; s0 += csb) {
+		if (overlap && s_fused && (hipEventRecord(ctx->ev_chunk, stream) != hipSuccess || hipStreamWaitEvent(s2, ctx->ev_chunk, 0) != hipSuccess))
+			return STENOS_ERROR_UNDEFINED;
+		for (uint64_t s0 = s_fused; s0 < s_tight; s0 += csb) {
 			const uint64_t s1 = s0 + csb < s_tight ? s0 + csb : s_tight;
 			if (s0 == 0)
 				ctx->mark(0, stream); // kernel timing: the first (normally only) encode_blocks launch of the safe zone
@@ -1505,6 +1522,8 @@ size_t finish_job(stenos_context_s* ctx)
 	if (kind == 1) {
 		const uint64_t total = ctx->h_total[0];
 		const uint32_t estatus = *(const uint32_t*)((const uint8_t*)ctx->h_total + 12);
+		if (estatus & codec::ENCODE_STATUS_CHAIN_TIMEOUT) // the fused path gave up waiting (never seen; reported rather than hung)
+			return STENOS_ERROR_UNDEFINED;
 		return (estatus || total > ctx->job_dst_size) ? STENOS_ERROR_DST_OVERFLOW : (size_t)total;
 	}
 	const uint32_t status = *(const uint32_t*)((const uint8_t*)ctx->h_total + 32);

@@ -47,6 +47,108 @@ __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ 
 	}
 }
 
+// ---- fused path -----------------------------------------------------------------------------------------
+// Chained scan over the superblocks: one 64-bit word each, bits 62-63 say what the low bits hold.
+constexpr uint64_t CHAIN_SIZE = 1ull << 62; // the bytes this superblock takes in the frame
+constexpr uint64_t CHAIN_END = 2ull << 62;  // the frame offset behind this superblock
+constexpr uint64_t CHAIN_MASK = (1ull << 62) - 1;
+constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 24;
+constexpr uint64_t CHAIN_FAILED = ~0ull;
+
+__device__ inline void chain_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t chain_get(uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Frame offset of superblock s, which takes `size` bytes (first_off for s == 0).  Run by one whole wavefront.
+// A superblock publishes its size before it looks at its predecessors and the predecessors all started earlier
+// (superblock numbers are tickets handed out in start order), so nobody waits for work that has not begun.  After
+// an absurd number of polls the wave gives up and CHAIN_FAILED is reported instead of hanging the device.
+__device__ uint64_t chain_offset(uint64_t* desc, uint64_t s, uint64_t size, uint64_t first_off)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	if (s == 0) {
+		if (lane == 0)
+			chain_put(desc, CHAIN_END | (first_off + size));
+		return first_off;
+	}
+	if (lane == 0)
+		chain_put(desc + s, CHAIN_SIZE | size);
+	uint64_t sum = 0, top = s; // superblocks [0, top) are still to be accounted for
+	for (;;) {
+		const bool valid = lane < top;
+		uint64_t d = CHAIN_SIZE; // lanes before superblock 0 add nothing
+		for (uint32_t spins = 0;; ++spins) {
+			if (valid)
+				d = chain_get(desc + (top - 1 - lane));
+			if (__ballot((d >> 62) == 0) == 0)
+				break;
+			if (spins > CHAIN_SPIN_LIMIT)
+				return CHAIN_FAILED;
+			__builtin_amdgcn_s_sleep(2);
+		}
+		const uint64_t ends = __ballot((d >> 62) == 2);
+		const uint32_t stop = ends ? (uint32_t)__builtin_ctzll(ends) : 64u; // nearest predecessor whose end offset is known
+		uint64_t v = lane <= stop ? (d & CHAIN_MASK) : 0;
+		for (int o = 32; o; o >>= 1)
+			v += __shfl_xor(v, o);
+		sum += v;
+		if (ends)
+			break;
+		top -= 64; // superblock 0 always publishes an end offset, so 64 or more remain here
+	}
+	if (lane == 0)
+		chain_put(desc + s, CHAIN_END | (sum + size));
+	return sum;
+}
+
+// One workgroup of FUSED_WAVES wavefronts per superblock: encode, chain, store (pipeline.h).
+template <uint32_t TT>
+__global__ __launch_bounds__(64 * FUSED_WAVES) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
+									uint64_t* __restrict__ desc, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
+{
+	const uint32_t T = TT ? TT : j.T;
+	const Layout L = make_layout(T, true);
+	const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total);
+	if (threadIdx.x == 0)
+		shared[0] = atomicAdd(ticket, 1u);
+	__syncthreads();
+	const uint64_t s = (uint32_t)__builtin_amdgcn_readfirstlane(shared[0]);
+	if (s >= nsb)
+		return;
+	uint32_t b0, b1;
+	fused_run_range(j.bps, w, &b0, &b1);
+	uint8_t* stage_w = stage + (s * FUSED_WAVES + w) * (uint64_t)run_cap;
+	const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w);
+	if ((threadIdx.x & 63u) == 0)
+		shared[1 + w] = n;
+	__syncthreads();
+	uint32_t run_size[FUSED_WAVES];
+	for (uint32_t k = 0; k < FUSED_WAVES; ++k)
+		run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(shared[1 + k]);
+	uint32_t code;
+	const uint32_t size = fused_superblock_size(j, run_size, &code);
+	if (w == 0) {
+		const uint64_t off = chain_offset(desc, s, size, j.header_bytes);
+		if (threadIdx.x == 0) {
+			shared[6] = (uint32_t)off;
+			shared[7] = (uint32_t)(off >> 32);
+			if (off == CHAIN_FAILED)
+				atomicOr(j.status, ENCODE_STATUS_CHAIN_TIMEOUT);
+			else if (s == nsb - 1) { // what scan_superblocks leaves behind for the ranges that follow
+				*carry = off + size;
+				j.sb_off[nsb] = off + size;
+				*j.total = off + size;
+			}
+		}
+	}
+	__syncthreads();
+	// readfirstlane yields an int: go through uint32_t or offsets beyond 2 GiB get sign-extended
+	const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(shared[6]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(shared[7]) << 32);
+	if (off == CHAIN_FAILED)
+		return;
+	fused_store(j, s, w, off, run_size, stage_w);
+}
+
 // One wavefront per superblock.
 __global__ __launch_bounds__(64) void plan_superblocks(FrameJob j, uint64_t s_begin)
 {
@@ -221,6 +323,35 @@ static hipError_t launch_encode_t(const FrameJob& j, uint64_t b_begin, uint64_t 
 			   j.bsize, j.binfo, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
 	return hipGetLastError();
 }
+
+template <uint32_t TT>
+static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
+{
+	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 64;
+	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(encode_superblocks<TT>, dim3((uint32_t)nsb), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
+			   ticket, carry);
+	return hipGetLastError();
+}
+
+// Superblocks [0, nsb) of the job, all of them bps full blocks with room for any encoding.  desc: nsb zeroed words,
+// ticket: one zeroed word, stage: stenos_k_fused_stage_bytes(); *carry receives the frame offset behind them.
+hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
+{
+	if (nsb == 0)
+		return hipSuccess;
+	switch (j.T) {
+		case 2: return launch_fused_t<2>(j, nsb, stage, desc, ticket, carry, stream);
+		case 4: return launch_fused_t<4>(j, nsb, stage, desc, ticket, carry, stream);
+		case 8: return launch_fused_t<8>(j, nsb, stage, desc, ticket, carry, stream);
+		default: return launch_fused_t<0>(j, nsb, stage, desc, ticket, carry, stream);
+	}
+}
+// the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)
+bool stenos_k_fused_supported(uint32_t T) { return FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 64 <= 160u * 1024u; }
+size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb) { return (size_t)nsb * FUSED_WAVES * fused_run_capacity(bps, T) + 64; }
 
 // blocks [b_begin, b_end) of the job (the tail block has index nfull)
 hipError_t stenos_k_launch_encode(const FrameJob& j, uint64_t b_begin, uint64_t b_end, hipStream_t stream)

@@ -18,7 +18,7 @@
 
 namespace codec {
 
-enum : uint32_t { ENCODE_STATUS_DST_OVERFLOW = 1 };
+enum : uint32_t { ENCODE_STATUS_DST_OVERFLOW = 1, ENCODE_STATUS_CHAIN_TIMEOUT = 2 };
 
 struct FrameJob {
 	const uint8_t* src;
@@ -223,6 +223,77 @@ WV_FN void resolve_capacity(Lds lds, const Layout& L, const FrameJob& j)
 	}
 	gstore_uniform64(j.sb_off + j.nsb, off);
 	gstore_uniform64(j.total, off);
+}
+
+// ---- fused path: superblocks made of full blocks that certainly have room -------------------------
+//
+// FUSED_WAVES wavefronts of one workgroup share a superblock: each encodes a run of consecutive blocks into a
+// contiguous staging stream (encode_run), the workgroup learns the superblock's frame offset (chained scan over
+// the superblocks, kernels.hip) and every wave copies its own run to its place in the frame.  No per-block
+// table, no second pass over HBM: the staging bytes are read back while they are still in the L2.
+constexpr uint32_t FUSED_WAVES = 4;
+WV_HD uint32_t fused_run_blocks(uint32_t bps) { return (bps + FUSED_WAVES - 1) / FUSED_WAVES; }
+WV_HD uint32_t fused_run_capacity(uint32_t bps, uint32_t T) { return align16(fused_run_blocks(bps) * max_block_bytes(T)) + 64; }
+
+// Number of leading superblocks whose capacity is large enough for any encoding, whatever the sizes of the
+// superblocks before them (every one stored as a copy): none of the reference's dst_end tests can fire there.
+WV_HD uint64_t safe_superblocks(uint64_t dst_size, uint64_t header, uint32_t bps, uint32_t T, uint64_t sb_bytes, uint64_t nsb)
+{
+	const uint64_t need_max = (uint64_t)(bps + 1) * (256 * T + (T + 1) / 2) + 288 * T + 64;
+	const uint64_t fixed = header + 4 + need_max;
+	uint64_t n = dst_size >= fixed ? (dst_size - fixed) / (sb_bytes + 4) + 1 : 0;
+	return n > nsb ? nsb : n;
+}
+
+// blocks [*b0, *b1) of a superblock are wave w's run
+WV_HD void fused_run_range(uint32_t bps, uint32_t w, uint32_t* b0, uint32_t* b1)
+{
+	const uint32_t per = fused_run_blocks(bps);
+	*b0 = w * per < bps ? w * per : bps;
+	*b1 = *b0 + per < bps ? *b0 + per : bps;
+}
+
+// BLOCK or COPY and the bytes the superblock takes in the frame (header included), from the run sizes
+WV_HD uint32_t fused_superblock_size(const FrameJob& j, const uint32_t* run_size, uint32_t* code)
+{
+	uint32_t csize = 0;
+	for (uint32_t w = 0; w < FUSED_WAVES; ++w)
+		csize += run_size[w];
+	*code = csize > j.sb_bytes ? 6u : 1u; // result > bytes -> memcpy (stenos.cpp:609-610); equal is kept
+	return 4 + (*code == 1 ? csize : j.sb_bytes);
+}
+
+// wave w's share of writing superblock s at frame offset off
+WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, const uint32_t* run_size, const uint8_t* stage_w)
+{
+	const U32 lane = lane_id();
+	uint32_t code;
+	const uint32_t csize = fused_superblock_size(j, run_size, &code) - 4;
+	uint8_t* base = j.dst + off;
+	if (w == 0) {
+		if (s == 0 && j.shift_byte != 0xFFFFFFFFu) { // frame header: [shift][bytes:7 LE] (+ [superblock size:4 LE]), stenos.cpp:862-874
+			const uint64_t v = (uint64_t)j.shift_byte | (j.total_bytes << 8);
+			gst8(j.dst, lane, (U32((uint32_t)v) >> ((lane & 3u) << 3)), lane < U32(4u));
+			gst8(j.dst, lane, (U32((uint32_t)(v >> 32)) >> ((lane & 3u) << 3)), (lane >= U32(4u)) & (lane < U32(8u)));
+			if (j.shift_byte == 255)
+				gst8(j.dst + 8, lane, U32(j.sb_bytes) >> ((lane & 3u) << 3), lane < U32(4u));
+		}
+		// superblock header [code][csize:3 LE] (stenos.cpp:613-615)
+		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
+		gstore_uniform64(j.sb_off + s, off);
+	}
+	if (code == 1) {
+		uint32_t before = 0;
+		for (uint32_t k = 0; k < w; ++k)
+			before += run_size[k];
+		copy_g2g_wide(base + 4 + before, stage_w, run_size[w]);
+	}
+	else {
+		uint32_t b0, b1;
+		fused_run_range(j.bps, w, &b0, &b1);
+		const uint32_t bs = 256 * j.T;
+		copy_g2g(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
+	}
 }
 
 // Pack step: PACK_WAVES wavefronts per superblock, each writing one contiguous quarter of the superblock's

@@ -108,6 +108,141 @@ WV_FN BlockInfo encode_block_job(Lds lds, const Layout& L, uint32_t T, const uin
 	return r;
 }
 
+// ---- a run of consecutive blocks -> one contiguous byte stream ------------------------------------
+//
+// A wavefront that encodes consecutive blocks appends their images to a contiguous stream in HBM (its share
+// of a superblock payload).  The stream is written in aligned 16-byte groups only: bytes of a block that do
+// not fill a group wait in the 16 bytes in front of the LDS image (Layout::out - 16 .. out) for the next one.
+struct RunStream {
+	uint8_t* base; // 16-byte aligned
+	uint32_t pos;  // bytes appended so far; the last pos % 16 of them are still in LDS
+};
+
+// append the n image bytes at LDS offset `out`
+WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t r = rs.pos & 15u;
+	const uint32_t groups = (r + n) >> 4;
+	uint8_t* g = rs.base + (rs.pos - r);
+	if (r == 0) {
+		for (uint32_t o = 0; o < groups; o += 64) {
+			U32 k = U32(o) + lane;
+			Pred p = k < U32(groups);
+			gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
+		}
+	}
+	else {
+		const uint32_t start = out - r;       // LDS offset of the first byte that is not in HBM yet
+		const uint32_t a0 = start & ~3u;      // five aligned dwords hold the 16 bytes of a group
+		const uint32_t sh = (start & 3u) * 8u;
+		for (uint32_t o = 0; o < groups; o += 64) {
+			U32 k = U32(o) + lane;
+			Pred p = k < U32(groups);
+			U32 la = U32(a0) + sel(p, k, U32(0u)) * 16u;
+			U32 d0 = lds_ld32(lds, la), d1 = lds_ld32(lds, la + 4u), d2 = lds_ld32(lds, la + 8u), d3 = lds_ld32(lds, la + 12u);
+			U128 v;
+			if (sh) {
+				U32 d4 = lds_ld32(lds, la + 16u);
+				v.x = (d0 >> U32(sh)) | (d1 << U32(32u - sh));
+				v.y = (d1 >> U32(sh)) | (d2 << U32(32u - sh));
+				v.z = (d2 >> U32(sh)) | (d3 << U32(32u - sh));
+				v.w = (d3 >> U32(sh)) | (d4 << U32(32u - sh));
+			}
+			else {
+				v.x = d0;
+				v.y = d1;
+				v.z = d2;
+				v.w = d3;
+			}
+			gst128(g, k * 16u, v, p);
+		}
+	}
+	// the bytes behind the last full group move in front of the image
+	const uint32_t r2 = (r + n) & 15u;
+	Pred t = lane < U32(r2);
+	U32 b = lds_ld8(lds, U32(out + n - r2) + sel(t, lane, U32(0u)));
+	wave_sync();
+	lds_st8(lds, U32(out - r2) + lane, b, t);
+	wave_sync();
+	rs.pos += n;
+}
+WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
+{
+	const U32 lane = lane_id();
+	const uint32_t r = rs.pos & 15u;
+	Pred t = lane < U32(r);
+	gst8(rs.base + (rs.pos - r), lane, lds_ld8(lds, U32(out - r) + sel(t, lane, U32(0u))), t);
+}
+
+// `nblocks` full blocks at src -> their encodings, back to back, at stage (16-byte aligned, room for
+// nblocks * max_block_bytes(T) + 16).  Ample capacity is assumed (the mini-LZ is always tried), which is
+// what the reference does for every superblock but the ones at the very end of a tight buffer.
+WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage)
+{
+	RunStream rs;
+	rs.base = stage;
+	rs.pos = 0;
+	for (uint32_t i = 0; i < nblocks; ++i) {
+		load_block(lds, L.in, src + (uint64_t)i * (256 * T), 256 * T);
+		wave_sync();
+		BlockInfo r = encode_full_block(lds, L, T, true);
+		stream_append(rs, lds, L.out, r.size);
+	}
+	stream_flush(rs, lds, L.out);
+	return rs.pos;
+}
+
+// HBM -> HBM copy of n bytes by one wave with 16-byte stores; src may be read up to 31 bytes past src + n
+// (and down to src & ~15), so it is only used on staging buffers that carry that slack.
+WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+	const uint32_t h = head < n ? head : n;
+	{
+		Pred p = lane < U32(h);
+		gst8(dst, lane, gld8(src, lane, p), p);
+	}
+	const uint32_t groups = (n - h) >> 4;
+	const uint32_t smis = (uint32_t)((uintptr_t)(src + h) & 15u);
+	const uint8_t* sbase = src + h - smis; // 16-byte aligned
+	const uint32_t dsel = smis >> 2, sh = (smis & 3u) * 8u;
+	for (uint32_t o = 0; o < groups; o += 64) {
+		U32 k = U32(o) + lane;
+		Pred p = k < U32(groups);
+		U128 a = gld128(sbase, k * 16u, p);
+		U128 v = a;
+		if (smis) {
+			U128 b = gld128(sbase, k * 16u + 16u, p);
+			// dwords dsel .. dsel + 4 of {a, b}
+			U32 t0 = dsel == 0 ? a.x : dsel == 1 ? a.y : dsel == 2 ? a.z : a.w;
+			U32 t1 = dsel == 0 ? a.y : dsel == 1 ? a.z : dsel == 2 ? a.w : b.x;
+			U32 t2 = dsel == 0 ? a.z : dsel == 1 ? a.w : dsel == 2 ? b.x : b.y;
+			U32 t3 = dsel == 0 ? a.w : dsel == 1 ? b.x : dsel == 2 ? b.y : b.z;
+			U32 t4 = dsel == 0 ? b.x : dsel == 1 ? b.y : dsel == 2 ? b.z : b.w;
+			if (sh) {
+				v.x = (t0 >> U32(sh)) | (t1 << U32(32u - sh));
+				v.y = (t1 >> U32(sh)) | (t2 << U32(32u - sh));
+				v.z = (t2 >> U32(sh)) | (t3 << U32(32u - sh));
+				v.w = (t3 >> U32(sh)) | (t4 << U32(32u - sh));
+			}
+			else {
+				v.x = t0;
+				v.y = t1;
+				v.z = t2;
+				v.w = t3;
+			}
+		}
+		gst128(dst + h, k * 16u, v, p);
+	}
+	const uint32_t done = h + groups * 16;
+	{
+		Pred p = lane < U32(n - done);
+		gst8(dst + done, lane, gld8(src + done, lane, p), p);
+	}
+}
+
 // The tail of a superblock payload: n < 256*T bytes -> [254] + partial block (block_compress.h:1277-1293).
 // info.full is unused for tails; info.need is the capacity requirement counted from the 254 byte.
 WV_FN BlockInfo encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t n, uint8_t* slot)

@@ -81,6 +81,11 @@ size_t emul_block_decompress(const uint8_t* src, size_t csize, size_t T, size_t 
 // The whole encode pipeline as capi.cpp enqueues it (encode_blocks, plan_superblocks, scan_superblocks,
 // resolve_frame, host zstd for a tiny last superblock, pack_frame), one "workgroup" after the other.
 
+static int g_fused = 1;
+static size_t g_last_fused = 0;
+void emul_set_fused(int on) { g_fused = on; }
+size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last frame sent through the fused path
+
 size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, int level)
 {
 	const size_t ERR_DST = (size_t)-6, ERR_PARAM = (size_t)-9;
@@ -141,18 +146,51 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	j.check_total = 1;
 	Layout L = make_layout((uint32_t)T, true);
 	uint8_t* lds = alloc_lds(L.total);
+	// fused zone (capi.cpp enqueue_compress): leading superblocks of full blocks with room for any encoding
+	uint64_t s_tight = safe_superblocks(dst_size, j.header_bytes, j.bps, j.T, sb, j.nsb);
+	if (j.tiny_last && s_tight > j.nsb - 1)
+		s_tight = j.nsb - 1;
+	uint64_t s_fused = 0, carry = j.header_bytes;
+	if (level >= 1 && g_fused)
+		s_fused = j.nfull / j.bps < s_tight ? j.nfull / j.bps : s_tight;
+	g_last_fused = s_fused;
+	if (s_fused) {
+		const uint32_t run_cap = fused_run_capacity(j.bps, j.T);
+		uint8_t* stage = nullptr;
+		if (posix_memalign((void**)&stage, 64, s_fused * FUSED_WAVES * (size_t)run_cap + 64))
+			return (size_t)-3;
+		uint8_t* wlds = alloc_lds(FUSED_WAVES * L.total);
+		for (uint64_t s = 0; s < s_fused; ++s) { // encode_superblocks
+			uint32_t run_size[FUSED_WAVES], code;
+			for (uint32_t w = 0; w < FUSED_WAVES; ++w) {
+				uint32_t b0, b1;
+				fused_run_range(j.bps, w, &b0, &b1);
+				run_size[w] = encode_run(wlds + w * L.total, L, j.T, src + (s * j.bps + b0) * bs, b1 - b0, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
+				if (run_size[w] + 48 > run_cap)
+					return (size_t)-1;
+			}
+			const uint32_t size = fused_superblock_size(j, run_size, &code);
+			for (uint32_t w = 0; w < FUSED_WAVES; ++w)
+				fused_store(j, s, w, carry, run_size, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
+			carry += size;
+		}
+		sboff[s_fused] = total = carry;
+		free(wlds);
+		free(stage);
+	}
+	const uint64_t b_first = s_fused * j.bps < j.nfull ? s_fused * j.bps : (s_fused >= j.nsb ? nblocks : j.nfull);
 	if (level >= 1)
-		for (uint64_t b = 0; b < nblocks; ++b) { // encode_blocks
+		for (uint64_t b = b_first; b < nblocks; ++b) { // encode_blocks
 			BlockInfo r = b < j.nfull ? encode_block_job(lds, L, j.T, src + b * bs, slots + b * (size_t)j.slot_stride, true)
 						 : encode_tail_job(lds, L, j.T, src + j.nfull * bs, j.tail_bytes, slots + j.nfull * (size_t)j.slot_stride);
 			bsize[b] = r.size;
 			binfo[b] = r.info;
 		}
-	for (uint64_t s = 0; s < j.nsb; ++s) // plan_superblocks
+	for (uint64_t s = s_fused; s < j.nsb; ++s) // plan_superblocks
 		plan_superblock(lds, L, j, s);
-	{ // scan_superblocks
-		uint64_t off = j.header_bytes;
-		for (uint64_t s = 0; s < j.nsb; ++s) {
+	if (s_fused < j.nsb) { // scan_superblocks
+		uint64_t off = carry;
+		for (uint64_t s = s_fused; s < j.nsb; ++s) {
 			sboff[s] = off;
 			off += 4 + (uint64_t)sbcsize[s];
 		}
@@ -196,7 +234,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	}
 	if (!result) {
 		uint8_t* plds = alloc_lds(pack_lds_bytes(j.bps));
-		for (uint64_t s = 0; s < j.nsb; ++s) // pack_frame
+		for (uint64_t s = s_fused; s < j.nsb; ++s) // pack_frame
 			for (uint32_t w = 0; w < PACK_WAVES; ++w)
 				pack_superblock(plds, j, s, w);
 		free(plds);
@@ -217,6 +255,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 }
 
 void emul_copy_g2g(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g(dst, src, (uint32_t)n); }
+void emul_copy_g2g_wide(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g_wide(dst, src, (uint32_t)n); }
 
 size_t emul_lds_bytes_encode(size_t T) { return make_layout((uint32_t)T, true).total; }
 size_t emul_lds_bytes_decode(size_t T) { return make_dec_layout((uint32_t)T).total; }

@@ -26,6 +26,10 @@ def emul():
     lib.emul_block_decompress.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int]
     lib.emul_copy_g2g.restype = None
     lib.emul_copy_g2g.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.emul_copy_g2g_wide.restype = None
+    lib.emul_copy_g2g_wide.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.emul_set_fused.restype = None
+    lib.emul_set_fused.argtypes = [c_int]
     return lib
 
 
@@ -75,20 +79,39 @@ def test_copy_any_alignment(emul):
                 assert not dst[:do].any() and not dst[do + n:].any(), (so, do, n)
 
 
+def test_wide_copy_any_alignment(emul):
+    """copy_g2g_wide (staging run -> frame): every source / destination misalignment, sizes around the
+    16-byte group; the source buffer carries the slack the routine is allowed to read."""
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, size=6000, dtype=np.uint8)
+    for so in range(0, 17):
+        for do in range(0, 18):
+            for n in (0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 1023, 1040, 3001):
+                dst = np.zeros(4096, dtype=np.uint8)
+                emul.emul_copy_g2g_wide(np_ptr(dst) + do, np_ptr(src) + so, n)
+                assert np.array_equal(dst[do:do + n], src[so:so + n]), (so, do, n)
+                assert not dst[:do].any() and not dst[do + n:].any(), (so, do, n)
+
+
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("T", [2, 4, 8, 3, 12])
-def test_frame_pipeline_and_capacity_rules(oracle, emul, T):
-    """The whole encode pipeline (encode_blocks, plan, scan, resolve, pack as capi.cpp enqueues them)
-    against the oracle's serial path for dst_size = bound, larger, and smaller: same frame or both an
-    error.  Covers the reference's capacity-dependent LZ attempt (block_compress.h:1214) and
+def test_frame_pipeline_and_capacity_rules(oracle, emul, T, fused):
+    """The whole encode pipeline (encode_superblocks for the leading superblocks with ample room, then
+    encode_blocks, plan, scan, resolve, pack, as capi.cpp enqueues them; fused=0: without the fused
+    kernel) against the oracle's serial path for dst_size = bound, larger, and smaller: same frame or
+    both an error.  Covers the reference's capacity-dependent LZ attempt (block_compress.h:1214) and
     dst_end tests (:1225, 1241, 1284) that decide BLOCK vs COPY near the end of the buffer."""
     from stenos_amd.datagen import splitmix64
+
+    emul.emul_set_fused(fused)
 
     emul.emul_compress_frame.restype = c_size_t
     emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
     from _libs import oracle_compress
 
     per = 131072 // (256 * T) * 256
-    replayed = 0
+    emul.emul_last_fused.restype = c_size_t
+    replayed = fused_superblocks = 0
     for kind in KINDS:
         for n in [1, 15, 17, 100, 255, 256, 257, 511, 1280, 4099, per - 1, per, per + 1, 2 * per + 300]:
             data = generate(kind, T, n, 77 + n)
@@ -101,11 +124,14 @@ def test_frame_pipeline_and_capacity_rules(oracle, emul, T):
                     out = np.zeros(cap + 64, dtype=np.uint8)
                     r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, level)
                     assert has_error(r1) == has_error(r2), (kind, n, cap, level, hex(r1), hex(r2))
+                    fused_superblocks += emul.emul_last_fused() if level == 1 else 0
                     if not has_error(r1):
                         assert r1 == r2 and np.array_equal(f1, out[:r2]), (kind, n, cap, level)
                         if level == 1 and cap == bound + 5000:
                             big = r1
                         if level == 1 and cap == bound and big is not None and r1 != big:
                             replayed += 1
+    emul.emul_set_fused(1)
+    assert (fused_superblocks > 0) == bool(fused)
     if T % 4 == 0:
         assert replayed > 0, "no case exercised the capacity replay"

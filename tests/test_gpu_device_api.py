@@ -1,6 +1,8 @@
 """Device-resident path (include/stenos_hip.h) at sizes the oracle cannot reach in seconds: size
 independent properties -- encode -> decode round trips on torch CUDA tensors, indexed and walked
 decoding agree, frames equal the host-ABI frames, compressed size is additive over superblocks."""
+import os
+
 import numpy as np
 import pytest
 
