@@ -8,7 +8,7 @@ import subprocess
 from ctypes import c_int, c_size_t, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libstenos.so")
+LIB_PATH = os.environ.get("STENOS_LIB_PATH") or os.path.join(HERE, "lib", "libstenos.so")  # override: experiments with other builds
 ERR_BASE = (1 << 64) - 100
 
 ERROR_NAMES = {

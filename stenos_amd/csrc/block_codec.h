@@ -31,8 +31,9 @@ struct Layout {
 	uint32_t out;     // encoded image: out_capacity(T) bytes, zeroed by the codec; the 16 bytes in front of it belong to RunStream
 	uint32_t rowinfo; // T*16 entries of 8 bytes
 	uint32_t plinfo;  // T entries of 4 bytes
-	uint32_t aux;     // 64 entries of 8 bytes (row statistics of the current plane group) / decoder scratch
-	uint32_t lz;      // mini-LZ: table 256*4 + chain count*4 + cur count*4
+	uint32_t aux;     // 64 entries of 8 bytes: row statistics of the current plane group (dead once the planes are analysed)
+	uint32_t lz;      // mini-LZ chain count*4 + cur count*4, on top of aux; its 256-entry table uses the not yet written image
+	uint32_t skip;    // mini-LZ: one bit per group that was left raw (32 bytes)
 	uint32_t total;
 	uint32_t dbg;     // diagnostics only (STENOS_DEBUG_PHASES): 1 = no LZ attempt, 2 = no emission, 4 = no analysis
 };
@@ -56,13 +57,16 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	o += T * 16 * 8;
 	L.plinfo = o;
 	o += align16(T * 4);
+	L.skip = o;
+	o += 32;
 	L.aux = o;
-	o += 64 * 8;
 	L.lz = o;
+	uint32_t scratch = 64 * 8;
 	if (with_lz && T % 4 == 0) {
-		uint32_t count = 256 * T / lz_width(T);
-		o += 256 * 4 + count * 8;
+		const uint32_t count = 256 * T / lz_width(T);
+		scratch = count * 8 > scratch ? count * 8 : scratch;
 	}
+	o += scratch;
 	L.total = align16(o);
 	L.dbg = 0;
 	return L;
@@ -420,7 +424,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	const U32 lane = lane_id();
 	const uint32_t B = lz_width(T);
 	const uint32_t count = 256 * T / B, nchunks = count / 64;
-	const uint32_t tab = L.lz, chain = L.lz + 1024, cur = chain + count * 4;
+	const uint32_t tab = L.out, chain = L.lz, cur = chain + count * 4; // the image is written last: its first KiB serves as the table
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
 
 	const uint32_t gq = quarter / 8 + 1; // first group whose start index exceeds count/4: the early-stop test runs after it
@@ -497,8 +501,8 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 
 	uint32_t failed = 0, max_failed = 3, produced = 0;
 	bool once = false;
-	// skip bits (one per group, up to 256 groups) live in the aux region, free after the analysis
-	const uint32_t skipbits = L.aux;
+	// skip bits (one per group, up to 256 groups)
+	const uint32_t skipbits = L.skip;
 	lds_st32(lds, U32(skipbits) + lane * 4u, U32(0u), lane < U32(8u));
 	wave_sync();
 	auto skipped = [&](const U32& h) -> Pred {
@@ -600,6 +604,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	}
 
 	// success: write the stream.  Items of a group follow its flag byte.
+	lds_zero(lds, L.out, out_capacity(T)); // the table is no longer needed
 	Lds out = lds + L.out;
 	lds_put_bits(out, U32(base * 8u), U32(BLOCK_LZ), lane == U32(0u));
 	uint32_t run = base + 1; // byte offset of the next chunk's first group flag
@@ -638,7 +643,6 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 // allow_lz mirrors the reference's capacity condition for the LZ attempt (block_compress.h:1214).
 WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
 {
-	lds_zero(lds, L.out, out_capacity(T));
 	const PlaneRegs regs = load_plane_regs(lds, L.in, T);
 	if (!(L.dbg & 4u))
 		for (uint32_t g = 0; g < T; g += 4)
@@ -655,8 +659,8 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 			r.info |= 1u << 31;
 			return r;
 		}
-		// nothing was written to the image on failure
 	}
+	lds_zero(lds, L.out, out_capacity(T)); // a failed LZ attempt leaves its table there
 	if (!(L.dbg & 2u))
 		emit_planes(lds, L, T, 0, 16, regs);
 	r.size = header_bytes(T) + full;

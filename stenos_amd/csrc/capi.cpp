@@ -320,7 +320,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	const uint32_t stride = stenos_k_slot_stride((uint32_t)T);
 	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
 	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
-	    !ctx->sboff.ensure((f.nsb + 2) * 8) || !ctx->misc.ensure(4096))
+	    !ctx->sboff.ensure((f.nsb + 8) * 8) || !ctx->misc.ensure(4096))
 		return STENOS_ERROR_ALLOC;
 	if (level >= 1 && !ctx->slots.ensure((nblocks + 1) * (size_t)stride))
 		return STENOS_ERROR_ALLOC;
@@ -389,7 +389,8 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	// Safe superblocks that consist of full blocks go through the fused kernel (encode + chained offsets + store in
 	// one launch); STENOS_NO_FUSED=1 sends them through encode / plan / scan / pack like the rest.
 	uint64_t s_fused = 0;
-	if (level >= 1 && stenos_k_fused_supported((uint32_t)T) && !getenv("STENOS_NO_FUSED")) {
+	// (offset 0 means "not published yet" to the fused kernel, so frames without a header stay on the other path)
+	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T) && !getenv("STENOS_NO_FUSED")) {
 		s_fused = f.nfull / f.bps < s_tight ? f.nfull / f.bps : s_tight;
 		if (s_fused) {
 			const size_t stage_bytes = stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused);
@@ -399,6 +400,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 			uint64_t* desc = ctx->chain.as<uint64_t>() + 1; // word 0: ticket counter
 			ctx->mark(0, stream);
 			if (hipMemsetAsync(ctx->chain.p, 0, (s_fused + 2) * 8, stream) != hipSuccess ||
+			    hipMemsetAsync(j.sb_off, 0, (s_fused + 8) * 8, stream) != hipSuccess ||
 			    stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, stream) != hipSuccess)
 				return STENOS_ERROR_UNDEFINED;
 			ctx->mark(1, stream);
@@ -565,7 +567,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	const size_t tmp_cap = bytes + 4 * (size_t)f.nsb + 64;
 	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
 	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
-	    !ctx->sboff.ensure((f.nsb + 2) * 8) || !ctx->misc.ensure(4096) || !ctx->qprod.ensure((f.nsb + 1) * 4) ||
+	    !ctx->sboff.ensure((f.nsb + 8) * 8) || !ctx->misc.ensure(4096) || !ctx->qprod.ensure((f.nsb + 1) * 4) ||
 	    !ctx->slots.ensure((nblocks + 1) * (size_t)stride) || !ctx->tmp1.ensure(tmp_cap))
 		return STENOS_ERROR_ALLOC;
 	uint8_t* misc = ctx->misc.as<uint8_t>();

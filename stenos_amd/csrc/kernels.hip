@@ -48,105 +48,205 @@ __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ 
 }
 
 // ---- fused path -----------------------------------------------------------------------------------------
-// Chained scan over the superblocks: one 64-bit word each, bits 62-63 say what the low bits hold.
-constexpr uint64_t CHAIN_SIZE = 1ull << 62; // the bytes this superblock takes in the frame
-constexpr uint64_t CHAIN_END = 2ull << 62;  // the frame offset behind this superblock
-constexpr uint64_t CHAIN_MASK = (1ull << 62) - 1;
-constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 24;
+// Frame offsets of the superblocks are produced while the encoders run.  Every workgroup publishes the bytes its
+// superblock takes (size[s], non-zero) as soon as the blocks are encoded; one scanner wavefront (workgroup 0) follows
+// the sizes in superblock order and publishes the offsets (sb_off[s], non-zero).  An encoder workgroup stores
+// superblock k only after it has encoded superblock k+1, so the offset is normally there when it asks for it.
+//
+// Progress: superblock numbers are tickets taken when the work on them starts, and between taking a ticket and
+// publishing its size a workgroup waits for nothing; the scanner is the first workgroup of the grid.  So every wait
+// ends.  A poll counter bounds them anyway: a wait that would hang the device is reported as an error instead.
+constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;
 constexpr uint64_t CHAIN_FAILED = ~0ull;
+#ifndef STENOS_FUSED_TICKETS
+#define STENOS_FUSED_TICKETS 1
+#endif
+constexpr uint32_t FUSED_TICKETS = STENOS_FUSED_TICKETS; // superblocks per encoder workgroup
 
 __device__ inline void chain_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline uint64_t chain_get(uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t chain_get(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Frame offset of superblock s, which takes `size` bytes (first_off for s == 0).  Run by one whole wavefront.
-// A superblock publishes its size before it looks at its predecessors and the predecessors all started earlier
-// (superblock numbers are tickets handed out in start order), so nobody waits for work that has not begun.  After
-// an absurd number of polls the wave gives up and CHAIN_FAILED is reported instead of hanging the device.
-__device__ uint64_t chain_offset(uint64_t* desc, uint64_t s, uint64_t size, uint64_t first_off)
+// one wavefront: sizes -> offsets, in order, up to 256 superblocks per round (four per lane, all loads in flight
+// together: the encoders finish a superblock every 0.1 us, a round trip to the sizes takes a few us)
+__device__ void chain_scanner(const FrameJob& j, uint64_t nsb, const uint64_t* size, uint64_t* carry)
 {
+	constexpr uint32_t PER = 4;
 	const uint32_t lane = threadIdx.x & 63u;
-	if (s == 0) {
-		if (lane == 0)
-			chain_put(desc, CHAIN_END | (first_off + size));
-		return first_off;
-	}
-	if (lane == 0)
-		chain_put(desc + s, CHAIN_SIZE | size);
-	uint64_t sum = 0, top = s; // superblocks [0, top) are still to be accounted for
-	for (;;) {
-		const bool valid = lane < top;
-		uint64_t d = CHAIN_SIZE; // lanes before superblock 0 add nothing
-		for (uint32_t spins = 0;; ++spins) {
-			if (valid)
-				d = chain_get(desc + (top - 1 - lane));
-			if (__ballot((d >> 62) == 0) == 0)
-				break;
-			if (spins > CHAIN_SPIN_LIMIT)
-				return CHAIN_FAILED;
-			__builtin_amdgcn_s_sleep(2);
+	__builtin_amdgcn_s_setprio(3);
+	uint64_t running = j.header_bytes, base = 0;
+	uint32_t spins = 0;
+#ifdef STENOS_EXP_STATS
+	uint64_t rounds = 0, empty = 0;
+#endif
+	while (base < nsb) {
+		uint64_t d[PER];
+		for (uint32_t q = 0; q < PER; ++q) {
+			const uint64_t idx = base + lane * PER + q;
+			d[q] = idx < nsb ? chain_get(size + idx) : 0;
 		}
-		const uint64_t ends = __ballot((d >> 62) == 2);
-		const uint32_t stop = ends ? (uint32_t)__builtin_ctzll(ends) : 64u; // nearest predecessor whose end offset is known
-		uint64_t v = lane <= stop ? (d & CHAIN_MASK) : 0;
-		for (int o = 32; o; o >>= 1)
-			v += __shfl_xor(v, o);
-		sum += v;
-		if (ends)
-			break;
-		top -= 64; // superblock 0 always publishes an end offset, so 64 or more remain here
+		uint32_t mine = 0; // leading sizes of this lane that are known
+		while (mine < PER && d[mine])
+			++mine;
+		const uint64_t partial = __ballot(mine < PER);
+		const uint32_t first = partial ? (uint32_t)__builtin_ctzll(partial) : 64u; // lanes before it are complete
+		const uint32_t ready = first == 64u ? 64u * PER : first * PER + (uint32_t)__shfl((int)mine, (int)first);
+		if (ready == 0) {
+#ifdef STENOS_EXP_STATS
+			++empty;
+#endif
+			if (++spins > CHAIN_SPIN_LIMIT) {
+				if (lane == 0)
+					atomicOr(j.status, ENCODE_STATUS_CHAIN_TIMEOUT);
+				return;
+			}
+			__builtin_amdgcn_s_sleep(2);
+			continue;
+		}
+		spins = 0;
+		const uint32_t take = lane < first ? PER : (lane == first ? mine : 0u); // entries of this lane inside the ready prefix
+		uint64_t sum = 0;
+		for (uint32_t q = 0; q < PER; ++q)
+			sum += q < take ? d[q] : 0;
+		uint64_t incl = sum;
+		for (uint32_t o = 1; o < 64; o <<= 1) {
+			const uint64_t up = __shfl_up(incl, o);
+			if (lane >= o)
+				incl += up;
+		}
+		uint64_t off = running + incl - sum;
+		for (uint32_t q = 0; q < PER; ++q)
+			if (q < take) {
+				chain_put(j.sb_off + base + lane * PER + q, off);
+				off += d[q];
+			}
+		running += __shfl(incl, 63);
+		base += ready;
+#ifdef STENOS_EXP_STATS
+		++rounds;
+#endif
 	}
-	if (lane == 0)
-		chain_put(desc + s, CHAIN_END | (sum + size));
-	return sum;
+	if (lane == 0) { // what scan_superblocks leaves behind for the ranges that follow
+#ifdef STENOS_EXP_STATS
+		j.sb_off[nsb + 1] = rounds | (empty << 32);
+#endif
+		*carry = running;
+		j.sb_off[nsb] = running;
+		*j.total = running;
+	}
 }
 
-// One workgroup of FUSED_WAVES wavefronts per superblock: encode, chain, store (pipeline.h).
-template <uint32_t TT>
-__global__ __launch_bounds__(64 * FUSED_WAVES) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
-									uint64_t* __restrict__ desc, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
+// offset of superblock s once the scanner has published it (every lane polls the same word)
+__device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 {
+#ifdef STENOS_EXP_NOWAIT
+	return j.header_bytes + s * 60000ull;
+#endif
+	for (uint32_t spins = 0; spins <= CHAIN_SPIN_LIMIT; ++spins) {
+		const uint64_t v = chain_get(j.sb_off + s);
+		// every lane read the same word: say so, or everything derived from the offset lives in vector registers
+		const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
+				     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+		if (off)
+			return off;
+		__builtin_amdgcn_s_sleep(4);
+	}
+	if ((threadIdx.x & 63u) == 0)
+		atomicOr(j.status, ENCODE_STATUS_CHAIN_TIMEOUT);
+	return CHAIN_FAILED;
+}
+
+// Workgroup 0: the scanner.  Every other workgroup: FUSED_WAVES wavefronts that take FUSED_TICKETS superblocks one
+// after the other -- encode (each wave a run of consecutive blocks into its staging stream), publish the size,
+// then store the previous superblock at its offset (pipeline.h, fused_store).
+template <uint32_t TT>
+__global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
+									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
+{
+	if (blockIdx.x == 0) {
+		if (threadIdx.x < 64)
+			chain_scanner(j, nsb, size, carry);
+		return;
+	}
 	const uint32_t T = TT ? TT : j.T;
 	const Layout L = make_layout(T, true);
-	const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total);
-	if (threadIdx.x == 0)
-		shared[0] = atomicAdd(ticket, 1u);
-	__syncthreads();
-	const uint64_t s = (uint32_t)__builtin_amdgcn_readfirstlane(shared[0]);
-	if (s >= nsb)
-		return;
+	const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total); // [0] ticket, [8 + 4*parity ..] run sizes
 	uint32_t b0, b1;
 	fused_run_range(j.bps, w, &b0, &b1);
-	uint8_t* stage_w = stage + (s * FUSED_WAVES + w) * (uint64_t)run_cap;
-	const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w);
-	if ((threadIdx.x & 63u) == 0)
-		shared[1 + w] = n;
-	__syncthreads();
-	uint32_t run_size[FUSED_WAVES];
-	for (uint32_t k = 0; k < FUSED_WAVES; ++k)
-		run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(shared[1 + k]);
-	uint32_t code;
-	const uint32_t size = fused_superblock_size(j, run_size, &code);
-	if (w == 0) {
-		const uint64_t off = chain_offset(desc, s, size, j.header_bytes);
-		if (threadIdx.x == 0) {
-			shared[6] = (uint32_t)off;
-			shared[7] = (uint32_t)(off >> 32);
-			if (off == CHAIN_FAILED)
-				atomicOr(j.status, ENCODE_STATUS_CHAIN_TIMEOUT);
-			else if (s == nsb - 1) { // what scan_superblocks leaves behind for the ranges that follow
-				*carry = off + size;
-				j.sb_off[nsb] = off + size;
-				*j.total = off + size;
-			}
+	uint64_t prev = CHAIN_FAILED; // superblock that is encoded but not stored yet
+	uint32_t prev_run[FUSED_WAVES];
+	for (uint32_t it = 0; it < FUSED_TICKETS; ++it) {
+		if (threadIdx.x == 0)
+			shared[0] = atomicAdd(ticket, 1u);
+		__syncthreads();
+		// readfirstlane yields an int: go through uint32_t or values beyond 2^31 get sign-extended
+		const uint64_t s = (uint32_t)__builtin_amdgcn_readfirstlane(shared[0]);
+		const bool work = s < nsb;
+		volatile uint32_t* runs = shared + 8 + 4 * (it & 1u);
+		if (work) {
+			uint8_t* stage_w = stage + (s * FUSED_WAVES + w) * (uint64_t)run_cap;
+#ifdef STENOS_EXP_STATS
+			const uint64_t te = __builtin_readcyclecounter();
+#endif
+			const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w);
+			if ((threadIdx.x & 63u) == 0)
+				runs[w] = n;
+#ifdef STENOS_EXP_STATS
+			if (threadIdx.x == 0)
+				atomicAdd((unsigned long long*)(j.sb_off + nsb + 6), (unsigned long long)(__builtin_readcyclecounter() - te));
+#endif
 		}
+		__syncthreads();
+		uint32_t run_size[FUSED_WAVES];
+		if (work) {
+			for (uint32_t k = 0; k < FUSED_WAVES; ++k)
+				run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(runs[k]);
+			uint32_t code;
+			const uint32_t bytes = fused_superblock_size(j, run_size, &code);
+			if (threadIdx.x == 0)
+				chain_put(size + s, bytes);
+		}
+		if (prev != CHAIN_FAILED) {
+#ifdef STENOS_EXP_STATS
+			const uint64_t t0 = __builtin_readcyclecounter();
+#endif
+			const uint64_t off = chain_wait(j, prev);
+#ifdef STENOS_EXP_STATS
+			const uint64_t t1 = __builtin_readcyclecounter();
+#endif
+			if (off == CHAIN_FAILED)
+				return;
+			fused_store(j, prev, w, off, prev_run, stage + (prev * FUSED_WAVES + w) * (uint64_t)run_cap);
+#ifdef STENOS_EXP_STATS
+			if (threadIdx.x == 0) {
+				atomicAdd((unsigned long long*)(j.sb_off + nsb + 2), (unsigned long long)(t1 - t0));
+				atomicAdd((unsigned long long*)(j.sb_off + nsb + 3), (unsigned long long)(__builtin_readcyclecounter() - t1));
+			}
+#endif
+		}
+		prev = work ? s : CHAIN_FAILED;
+		for (uint32_t k = 0; k < FUSED_WAVES; ++k)
+			prev_run[k] = run_size[k];
+		if (!work)
+			break;
 	}
-	__syncthreads();
-	// readfirstlane yields an int: go through uint32_t or offsets beyond 2 GiB get sign-extended
-	const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(shared[6]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(shared[7]) << 32);
-	if (off == CHAIN_FAILED)
-		return;
-	fused_store(j, s, w, off, run_size, stage_w);
+	if (prev != CHAIN_FAILED) {
+#ifdef STENOS_EXP_STATS
+		const uint64_t t0 = __builtin_readcyclecounter();
+#endif
+		const uint64_t off = chain_wait(j, prev);
+#ifdef STENOS_EXP_STATS
+		const uint64_t t1 = __builtin_readcyclecounter();
+#endif
+		if (off != CHAIN_FAILED)
+			fused_store(j, prev, w, off, prev_run, stage + (prev * FUSED_WAVES + w) * (uint64_t)run_cap);
+#ifdef STENOS_EXP_STATS
+		if (threadIdx.x == 0) {
+			atomicAdd((unsigned long long*)(j.sb_off + nsb + 4), (unsigned long long)(t1 - t0));
+			atomicAdd((unsigned long long*)(j.sb_off + nsb + 5), (unsigned long long)(__builtin_readcyclecounter() - t1));
+		}
+#endif
+	}
 }
 
 // One wavefront per superblock.
@@ -331,13 +431,15 @@ static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage
 	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
-	hipLaunchKernelGGL(encode_superblocks<TT>, dim3((uint32_t)nsb), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
+	const uint32_t grid = (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS) + 1; // + the scanner
+	hipLaunchKernelGGL(encode_superblocks<TT>, dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
 			   ticket, carry);
 	return hipGetLastError();
 }
 
 // Superblocks [0, nsb) of the job, all of them bps full blocks with room for any encoding.  desc: nsb zeroed words,
-// ticket: one zeroed word, stage: stenos_k_fused_stage_bytes(); *carry receives the frame offset behind them.
+// ticket: one zeroed word, j.sb_off[0, nsb] zeroed, stage: stenos_k_fused_stage_bytes(); *carry receives the frame
+// offset behind them.
 hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
 {
 	if (nsb == 0)

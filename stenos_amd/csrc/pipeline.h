@@ -228,10 +228,13 @@ WV_FN void resolve_capacity(Lds lds, const Layout& L, const FrameJob& j)
 // ---- fused path: superblocks made of full blocks that certainly have room -------------------------
 //
 // FUSED_WAVES wavefronts of one workgroup share a superblock: each encodes a run of consecutive blocks into a
-// contiguous staging stream (encode_run), the workgroup learns the superblock's frame offset (chained scan over
-// the superblocks, kernels.hip) and every wave copies its own run to its place in the frame.  No per-block
-// table, no second pass over HBM: the staging bytes are read back while they are still in the L2.
-constexpr uint32_t FUSED_WAVES = 4;
+// contiguous staging stream (encode_run), the workgroup learns the superblock's frame offset (sb_off[s], written
+// by the scanner wavefront of kernels.hip) and every wave copies its own run to its place in the frame.  No
+// per-block table and no separate pack pass.
+#ifndef STENOS_FUSED_WAVES
+#define STENOS_FUSED_WAVES 4
+#endif
+constexpr uint32_t FUSED_WAVES = STENOS_FUSED_WAVES;
 WV_HD uint32_t fused_run_blocks(uint32_t bps) { return (bps + FUSED_WAVES - 1) / FUSED_WAVES; }
 WV_HD uint32_t fused_run_capacity(uint32_t bps, uint32_t T) { return align16(fused_run_blocks(bps) * max_block_bytes(T)) + 64; }
 
@@ -280,8 +283,10 @@ WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, 
 		}
 		// superblock header [code][csize:3 LE] (stenos.cpp:613-615)
 		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
-		gstore_uniform64(j.sb_off + s, off);
 	}
+#ifdef STENOS_EXP_NOCOPY
+	return;
+#endif
 	if (code == 1) {
 		uint32_t before = 0;
 		for (uint32_t k = 0; k < w; ++k)

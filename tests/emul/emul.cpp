@@ -170,6 +170,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 					return (size_t)-1;
 			}
 			const uint32_t size = fused_superblock_size(j, run_size, &code);
+			sboff[s] = carry; // chain_scanner
 			for (uint32_t w = 0; w < FUSED_WAVES; ++w)
 				fused_store(j, s, w, carry, run_size, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
 			carry += size;
