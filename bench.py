@@ -181,7 +181,7 @@ def main():
 
     out = None
     if rank == 0:
-        # roofline of the dominant kernel (encode_blocks): algorithmic bytes = N read + C written per launch
+        # roofline of the dominant kernel (encode_superblocks, the fused encoder): algorithmic bytes = N read + C written per launch
         algo = nbytes + r["csize"]
         achieved = algo / (r["kenc_ms"] / 1e3) / 1e9 if r["kenc_ms"] > 0 else 0.0
         traffic = None
@@ -189,7 +189,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("encode_blocks_hbm_bytes_per_launch")
+                    traffic = json.load(f).get("encode_superblocks_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -211,7 +211,7 @@ def main():
             "compression_ratio": round(ratio, 4),
             "encode_gbps": round(nbytes * args.steps / r["enc_s"] / 1e9, 3),
             "decode_gbps": round(nbytes * args.steps / r["dec_s"] / 1e9, 3),
-            "roofline": {"bound": "hbm", "kernel": "encode_blocks", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "encode_superblocks", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo, "kernel_ms": round(r["kenc_ms"], 4),
                          "decode_superblocks": {"achieved": round(algo / (r["kdec_ms"] / 1e3) / 1e9, 2) if r["kdec_ms"] > 0 else 0.0,

@@ -13,7 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 input_bytes = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0 * (1 << 30)  # bytes of the profiled workload
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for p in sorted(glob.glob(os.path.join(ROOT, "gpurun_out/pmc/p*/*/*_counter_collection.csv"))):
+# gpurun merges new outputs into the local directory: keep only the newest collection of every pass
+newest = {}
+for p in glob.glob(os.path.join(ROOT, "gpurun_out/pmc/p*/*/*_counter_collection.csv")):
+    d = os.path.dirname(p)
+    if d not in newest or os.path.getmtime(p) > os.path.getmtime(newest[d]):
+        newest[d] = p
+for p in sorted(newest.values()):
     for r in csv.DictReader(open(p)):
         k = r["Kernel_Name"]
         if "anonymous namespace" not in k or "elementwise_kernel_with_index" in k or "at::native" in k:
@@ -32,7 +38,7 @@ scale = 1.0
 if "decode_superblocks" in out and out["decode_superblocks"].get("WRITE_SIZE"):
     scale = input_bytes / (out["decode_superblocks"]["WRITE_SIZE"] * 1024)
 res["counter_coverage"] = round(1.0 / scale, 4)
-for k in ("encode_blocks", "pack_frame", "decode_superblocks"):
+for k in ("encode_superblocks", "encode_blocks", "pack_frame", "decode_superblocks"):
     if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
         res[f"{k}_hbm_bytes_per_launch"] = int(scale * (2 * out[k]["FETCH_SIZE"] * 1024 + out[k]["WRITE_SIZE"] * 1024))
         res[f"{k}_hbm_read_bytes"] = int(scale * 2 * out[k]["FETCH_SIZE"] * 1024)
