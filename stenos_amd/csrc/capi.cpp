@@ -322,8 +322,6 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
 	    !ctx->sboff.ensure((f.nsb + 8) * 8) || !ctx->misc.ensure(4096))
 		return STENOS_ERROR_ALLOC;
-	if (level >= 1 && !ctx->slots.ensure((nblocks + 1) * (size_t)stride))
-		return STENOS_ERROR_ALLOC;
 
 	const size_t last_bytes = bytes - (f.nsb - 1) * f.sb;
 	const bool tiny_last = level >= 1 && last_bytes < 128; // small input: direct zstd (stenos.cpp:435-437)
@@ -380,32 +378,35 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	};
 
 	uint64_t* d_carry = (uint64_t*)(misc + 24);
-	const uint32_t init[2] = { 0u, 0xFFFFFFFFu }; // status, first_flagged
-	const uint64_t carry0 = header;
-	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
-	    hipMemcpyAsync(d_carry, &carry0, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
-	    hipMemcpyAsync(j.total, &carry0, 8, hipMemcpyHostToDevice, stream) != hipSuccess)
-		return STENOS_ERROR_UNDEFINED;
-	// Safe superblocks that consist of full blocks go through the fused kernel (encode + chained offsets + store in
-	// one launch); STENOS_NO_FUSED=1 sends them through encode / plan / scan / pack like the rest.
-	uint64_t s_fused = 0;
+	// Safe superblocks that consist of full blocks go through the fused kernel (encode + offsets + store in one
+	// launch); STENOS_NO_FUSED=1 sends them through encode / plan / scan / pack like the rest.
 	// (offset 0 means "not published yet" to the fused kernel, so frames without a header stay on the other path)
-	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T) && !getenv("STENOS_NO_FUSED")) {
+	uint64_t s_fused = 0;
+	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T) && !getenv("STENOS_NO_FUSED"))
 		s_fused = f.nfull / f.bps < s_tight ? f.nfull / f.bps : s_tight;
-		if (s_fused) {
-			const size_t stage_bytes = stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused);
-			if (!ctx->slots.ensure(stage_bytes) || !ctx->chain.ensure((s_fused + 2) * 8))
-				return STENOS_ERROR_ALLOC;
-			j.slots = ctx->slots.as<uint8_t>();
-			uint64_t* desc = ctx->chain.as<uint64_t>() + 1; // word 0: ticket counter
-			ctx->mark(0, stream);
-			if (hipMemsetAsync(ctx->chain.p, 0, (s_fused + 2) * 8, stream) != hipSuccess ||
-			    hipMemsetAsync(j.sb_off, 0, (s_fused + 8) * 8, stream) != hipSuccess ||
-			    stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
-			ctx->mark(1, stream);
-		}
+	// One arena serves both: the staging streams of the fused superblocks, then (the fused kernel is done by
+	// then) the 16-byte aligned slots of the remaining blocks, addressed by their absolute block number.
+	const uint64_t b_unfused = first_block(s_fused);
+	if (level >= 1) {
+		const size_t stage_bytes = s_fused ? stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused) : 0;
+		const size_t slot_bytes = (size_t)(nblocks_all - b_unfused + 1) * stride;
+		if (!ctx->slots.ensure(stage_bytes > slot_bytes ? stage_bytes : slot_bytes))
+			return STENOS_ERROR_ALLOC;
+		j.slots = ctx->slots.as<uint8_t>() - b_unfused * (uint64_t)stride;
 	}
+	if (s_fused) {
+		if (!ctx->chain.ensure((s_fused + 2) * 8))
+			return STENOS_ERROR_ALLOC;
+		uint64_t* desc = ctx->chain.as<uint64_t>() + 1; // word 0: ticket counter
+		if (stenos_k_launch_init(misc, header, ctx->chain.as<uint64_t>(), s_fused + 2, j.sb_off, s_fused + 8, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		ctx->mark(0, stream);
+		if (stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		ctx->mark(1, stream);
+	}
+	else if (stenos_k_launch_init(misc, header, nullptr, 0, nullptr, 0, stream) != hipSuccess)
+		return STENOS_ERROR_UNDEFINED;
 	if (s_tight > s_fused) {
 		// Measured on MI355X (8 GiB int32): overlapping the pack of chunk k with the encoding of chunk k+1 on a
 		// second stream gains nothing (748-802 GB/s against 725-764 GB/s for one chunk; chunks below 128 MiB are
@@ -600,12 +601,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	j.fixed_capacity = 1;
 	j.qprod = ctx->qprod.as<uint32_t>();
 	uint64_t* d_carry = (uint64_t*)(misc + 24);
-	const uint32_t init[2] = { 0u, 0xFFFFFFFFu };
-	const uint64_t zero = 0;
-	if (hipMemcpyAsync(misc + 12, init, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
-	    hipMemcpyAsync(d_carry, &zero, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
-	    hipMemcpyAsync(j.total, &zero, 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
-	    stenos_k_launch_encode(j, 0, nblocks, stream) != hipSuccess || stenos_k_launch_plan(j, 0, f.nsb, stream) != hipSuccess ||
+	if (stenos_k_launch_init(misc, 0, nullptr, 0, nullptr, 0, stream) != hipSuccess || stenos_k_launch_encode(j, 0, nblocks, stream) != hipSuccess || stenos_k_launch_plan(j, 0, f.nsb, stream) != hipSuccess ||
 	    stenos_k_launch_scan(j, 0, f.nsb, d_carry, stream) != hipSuccess || stenos_k_launch_pack(j, 0, f.nsb, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	std::vector<uint8_t> code(f.nsb);
@@ -1488,9 +1484,15 @@ size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes)
 	if (bytesoftype == 0 || bytesoftype > kMaxT)
 		return 0;
 	const size_t bs = bytesoftype * 256;
+	const size_t sb = base_superblock(bs);
 	const size_t nblocks = bytes / bs + 2;
-	const size_t nsb = bytes / base_superblock(bs) + 2;
-	return nblocks * (stenos_k_slot_stride((uint32_t)bytesoftype) + 8) + nsb * 13 + 4096;
+	const size_t nsb = bytes / sb + 2;
+	const uint32_t T = (uint32_t)bytesoftype;
+	// the arena: staging streams of the fused encoder (about the input size) or, where that kernel does not apply,
+	// one padded slot per block; then 12 bytes of tables per block and 37 per superblock (default superblock size)
+	const size_t arena = stenos_k_fused_supported(T) ? stenos_k_fused_stage_bytes(T, (uint32_t)(sb / bs), nsb) + 2 * (sb / bs + 1) * stenos_k_slot_stride(T)
+							 : nblocks * (size_t)stenos_k_slot_stride(T);
+	return arena + nblocks * 12 + nsb * 37 + 4096;
 }
 
 size_t stenos_hip_compress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream)

@@ -47,6 +47,25 @@ __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ 
 	}
 }
 
+// Start of a compression job: misc = { total = first_off, [8,12) untouched, status = 0, first_flagged = none,
+// [20,24) untouched, scan carry = first_off } and two word ranges cleared (the fused path's tickets / sizes and
+// the superblock offsets it polls).  One launch instead of five small copies and fills.
+__global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint64_t first_off, uint64_t* __restrict__ z1, uint64_t n1,
+						 uint64_t* __restrict__ z2, uint64_t n2)
+{
+	const uint64_t i = blockIdx.x * 256ull + threadIdx.x, step = gridDim.x * 256ull;
+	if (i == 0) {
+		*(uint64_t*)misc = first_off;
+		*(uint32_t*)(misc + 12) = 0u;
+		*(uint32_t*)(misc + 16) = 0xFFFFFFFFu;
+		*(uint64_t*)(misc + 24) = first_off;
+	}
+	for (uint64_t k = i; k < n1; k += step)
+		z1[k] = 0;
+	for (uint64_t k = i; k < n2; k += step)
+		z2[k] = 0;
+}
+
 // ---- fused path -----------------------------------------------------------------------------------------
 // Frame offsets of the superblocks are produced while the encoders run.  Every workgroup publishes the bytes its
 // superblock takes (size[s], non-zero) as soon as the blocks are encoded; one scanner wavefront (workgroup 0) follows
@@ -421,6 +440,15 @@ static hipError_t launch_encode_t(const FrameJob& j, uint64_t b_begin, uint64_t 
 	}
 	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, b_begin, b_end, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride,
 			   j.bsize, j.binfo, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
+	return hipGetLastError();
+}
+
+hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1, uint64_t n1, uint64_t* z2, uint64_t n2, hipStream_t stream)
+{
+	const uint64_t words = n1 > n2 ? n1 : n2;
+	uint32_t grid = (uint32_t)((words + 255) / 256);
+	grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+	hipLaunchKernelGGL(init_job, dim3(grid), dim3(256), 0, stream, misc, first_off, z1, n1, z2, n2);
 	return hipGetLastError();
 }
 
