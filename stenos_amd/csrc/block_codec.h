@@ -153,6 +153,70 @@ WV_FN U32 compact_unflagged(const U32& x, const U32& f)
 // encoder
 // ------------------------------------------------------------------------------------------------
 
+// Stage 1 of the analysis for bytesoftype 4, all four planes at once.  The quad of lanes that holds a row of 16
+// elements transposes its plane words (4 x 4 dwords, two DPP exchanges) so that lane 4r+q owns the 16 bytes of row r
+// of plane q; minima, maxima, delta ranges and the two run counts then need no cross-lane step at all, and constant
+// planes cost nothing extra (their rows come out as mx == mn with equal minima, which is what makes a plane SAME).
+// Same statistics, same L.aux entries (plane*16 + row) as the plane-at-a-time form below.
+WV_FN U32 bytes_min16(const U32& e0, const U32& o0, const U32& e1, const U32& o1, const U32& e2, const U32& o2, const U32& e3, const U32& o3)
+{
+	U32 m = pk_min_u16(pk_min_u16(pk_min_u16(e0, o0), pk_min_u16(e1, o1)), pk_min_u16(pk_min_u16(e2, o2), pk_min_u16(e3, o3)));
+	return umin(m & 0xFFFFu, m >> 16);
+}
+WV_FN U32 bytes_max16(const U32& e0, const U32& o0, const U32& e1, const U32& o1, const U32& e2, const U32& o2, const U32& e3, const U32& o3)
+{
+	U32 m = pk_max_u16(pk_max_u16(pk_max_u16(e0, o0), pk_max_u16(e1, o1)), pk_max_u16(pk_max_u16(e2, o2), pk_max_u16(e3, o3)));
+	return umax(m & 0xFFFFu, m >> 16);
+}
+WV_FN void analyse_rows_int32(Lds lds, const Layout& L, const PlaneRegs& regs)
+{
+	const U32 lane = lane_id();
+	const U32 q = lane & 3u;
+	// 4 x 4 transpose inside the quad: b[k] = plane-q word of the quad's lane k (elements 4k..4k+3 of the row)
+	U32 b[4];
+	{
+		Pred odd = (q & 1u) == U32(1u), hi = (q & 2u) == U32(2u);
+		U32 r0 = shfl_xor(sel(odd, regs.w[0], regs.w[1]), 1), r1 = shfl_xor(sel(odd, regs.w[2], regs.w[3]), 1);
+		U32 c0 = sel(odd, r0, regs.w[0]), c1 = sel(odd, regs.w[1], r0);
+		U32 c2 = sel(odd, r1, regs.w[2]), c3 = sel(odd, regs.w[3], r1);
+		U32 s0 = shfl_xor(sel(hi, c0, c2), 2), s1 = shfl_xor(sel(hi, c1, c3), 2);
+		b[0] = sel(hi, s0, c0);
+		b[2] = sel(hi, c2, s0);
+		b[1] = sel(hi, s1, c1);
+		b[3] = sel(hi, c3, s1);
+	}
+	// deltas against the previous byte in plane order; before a row comes the last byte of the row above (lane - 4),
+	// before the plane 0 (block_compress.h:399-401)
+	U32 prev = shfl_up(b[3], 4, 0) >> 24;
+	U32 d[4];
+	d[0] = bytes_sub(b[0], (b[0] << 8) | prev);
+	for (int k = 1; k < 4; ++k)
+		d[k] = bytes_sub(b[k], (b[k] << 8) | (b[k - 1] >> 24));
+	// runs: byte == previous byte (:268-275); delta == previous delta, 0 before the row's first column (:248-255, 449-458)
+	U32 nrle(0u), ndrle(0u);
+	for (int k = 0; k < 4; ++k) {
+		nrle = nrle + popc(bytes_zero_mask(d[k]));
+		U32 pd = k ? (d[k - 1] >> 24) : U32(0u);
+		ndrle = ndrle + popc(bytes_zero_mask(d[k] ^ ((d[k] << 8) | pd)));
+	}
+	// ranges in signed order (:407-411): even and odd bytes side by side as 16-bit halves
+	U32 e[4], o[4], de[4], dod[4];
+	for (int k = 0; k < 4; ++k) {
+		U32 s = b[k] ^ 0x80808080u, ds = d[k] ^ 0x80808080u;
+		e[k] = s & 0x00FF00FFu;
+		o[k] = (s >> 8) & 0x00FF00FFu;
+		de[k] = ds & 0x00FF00FFu;
+		dod[k] = (ds >> 8) & 0x00FF00FFu;
+	}
+	U32 mn = bytes_min16(e[0], o[0], e[1], o[1], e[2], o[2], e[3], o[3]);
+	U32 mx = bytes_max16(e[0], o[0], e[1], o[1], e[2], o[2], e[3], o[3]);
+	U32 dmn = bytes_min16(de[0], dod[0], de[1], dod[1], de[2], dod[2], de[3], dod[3]);
+	U32 dmx = bytes_max16(de[0], dod[0], de[1], dod[1], de[2], dod[2], de[3], dod[3]);
+	U32 addr = U32(L.aux) + (q * 16u + (lane >> 2)) * 8u;
+	lds_st32(lds, addr, mn | (mx << 8) | (dmn << 16) | (dmx << 24), pred_all(true));
+	lds_st32(lds, addr + 4u, nrle | (ndrle << 16), pred_all(true));
+}
+
 // rowinfo entry: lo = hdr | min<<8 | poff<<16 ; hi = minpos | emitmin<<12 | eq<<13
 // plinfo entry : type | size_or_offset<<8
 
@@ -161,6 +225,10 @@ WV_FN U32 compact_unflagged(const U32& x, const U32& f)
 WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs)
 {
 	const U32 lane = lane_id();
+	if (regs.valid && np == 4) {
+		analyse_rows_int32(lds, L, regs);
+	}
+	else
 	// stage 1: element lanes, one plane at a time -> per-row statistics in L.aux
 	for (uint32_t pj = 0; pj < np; ++pj) {
 		U32 w = fetch_plane_word(lds, L.in, T, g + pj, regs);
@@ -299,7 +367,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 	{
 		Pred valid = lane < U32(T);
 		U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
-		lds_put_bits(out, U32(base * 8u) + lane * 4u, pi & 0xFu, valid);
+		lds_put_small(out, U32(base * 8u) + lane * 4u, pi & 0xFu, valid);
 	}
 	// row lanes: row-header nibbles, mins, SAME byte
 	for (uint32_t g = 0; g < T; g += 4) {
@@ -314,9 +382,9 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		Pred normal = valid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
 		Pred act = r < U32(lines);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
-		lds_put_bits(out, pbase * 8u + r * 4u, hdr, normal & act); // (:768-779, 758-762)
+		lds_put_small(out, pbase * 8u + r * 4u, hdr, normal & act); // (:768-779, 758-762)
 		Pred emit = ((hi >> 12) & 1u) == U32(1u);
-		lds_put_bits(out, (pbase + (hi & 0xFFFu)) * 8u, minv, normal & emit);
+		lds_put_small(out, (pbase + (hi & 0xFFFu)) * 8u, minv, normal & emit);
 		// mins rle mask (:765): bit r = min equals previous min
 		uint64_t eqb = ballot(((hi >> 13) & 1u) == U32(1u));
 		U32 m16 = sel(pl == U32(0u), U32((uint32_t)(eqb & 0xFFFF)),
@@ -324,7 +392,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 				  sel(pl == U32(2u), U32((uint32_t)((eqb >> 32) & 0xFFFF)), U32((uint32_t)(eqb >> 48)))));
 		lds_put_bits(out, (pbase + 8u) * 8u, m16, valid & (type == U32(PLANE_NORMAL_RLE)) & (r == U32(0u)));
 		// SAME: the plane's byte; every row has mx == mn so minv is that byte (:747-750)
-		lds_put_bits(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
+		lds_put_small(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
 	}
 	// element lanes: row payloads.  Every lane contributes one piece per plane (its 4 raw bytes, its 4
 	// packed values or its rle literals); rle rows add their 4 mask bits.
@@ -365,7 +433,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 			U32 before = quad_add(sel(isr, nlit << (q << 3), U32(0u))); // literal counts of the quad's lanes
 			U32 prior = (before & ((U32(1u) << (q << 3)) - 1u));
 			prior = (prior & 0xFFu) + ((prior >> 8) & 0xFFu) + ((prior >> 16) & 0xFFu);
-			lds_put_bits(out, rbase * 8u + q * 4u, f, isr);
+			lds_put_small(out, rbase * 8u + q * 4u, f, isr);
 			piece = sel(isr, compact_unflagged(sel(is7, w, dw), f), piece);
 			bitpos = sel(isr, (rbase + 2u + prior) * 8u, bitpos);
 			emit = emit | (isr & (nlit != U32(0u)));

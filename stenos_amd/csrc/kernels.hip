@@ -179,7 +179,7 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 // then store the previous superblock at its offset (pipeline.h, fused_store).
 template <uint32_t TT>
 __global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
-									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
+									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry, uint32_t dbg)
 {
 	if (blockIdx.x == 0) {
 		if (threadIdx.x < 64)
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJ
 		return;
 	}
 	const uint32_t T = TT ? TT : j.T;
-	const Layout L = make_layout(T, true);
+	Layout L = make_layout(T, true);
+	L.dbg = dbg; // diagnostics only, 0 in normal operation
 	const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total); // [0] ticket, [8 + 4*parity ..] run sizes
 	uint32_t b0, b1;
@@ -461,7 +462,7 @@ static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage
 		return e;
 	const uint32_t grid = (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS) + 1; // + the scanner
 	hipLaunchKernelGGL(encode_superblocks<TT>, dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
-			   ticket, carry);
+			   ticket, carry, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
 	return hipGetLastError();
 }
 

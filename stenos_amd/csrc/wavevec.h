@@ -127,6 +127,27 @@ WV_FN U32 popc(const U32& a)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)__builtin_popcount(a.l[i]);
 	return r;
 }
+// min / max of the two 16-bit halves, each half on its own (v_pk_min_u16 / v_pk_max_u16)
+WV_FN U32 pk_min_u16(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint32_t lo = (a.l[i] & 0xFFFFu) < (b.l[i] & 0xFFFFu) ? (a.l[i] & 0xFFFFu) : (b.l[i] & 0xFFFFu);
+		uint32_t hi = (a.l[i] >> 16) < (b.l[i] >> 16) ? (a.l[i] >> 16) : (b.l[i] >> 16);
+		r.l[i] = lo | (hi << 16);
+	}
+	return r;
+}
+WV_FN U32 pk_max_u16(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint32_t lo = (a.l[i] & 0xFFFFu) > (b.l[i] & 0xFFFFu) ? (a.l[i] & 0xFFFFu) : (b.l[i] & 0xFFFFu);
+		uint32_t hi = (a.l[i] >> 16) > (b.l[i] >> 16) ? (a.l[i] >> 16) : (b.l[i] >> 16);
+		r.l[i] = lo | (hi << 16);
+	}
+	return r;
+}
 // number of bits needed to represent a (0 for 0)
 WV_FN U32 bitlen(const U32& a)
 {
@@ -382,6 +403,9 @@ WV_FN U32 lane_id()
 WV_FN U32 umin(U32 a, U32 b) { return a < b ? a : b; }
 WV_FN U32 umax(U32 a, U32 b) { return a > b ? a : b; }
 WV_FN U32 popc(U32 a) { return (U32)__builtin_popcount(a); }
+typedef unsigned short wv_us2 __attribute__((ext_vector_type(2)));
+WV_FN U32 pk_min_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_elementwise_min(__builtin_bit_cast(wv_us2, a), __builtin_bit_cast(wv_us2, b))); }
+WV_FN U32 pk_max_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_elementwise_max(__builtin_bit_cast(wv_us2, a), __builtin_bit_cast(wv_us2, b))); }
 WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
 WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
@@ -570,6 +594,12 @@ WV_FN void lds_put_bits(Lds m, const U32& bitpos, const U32& value, const Pred& 
 	lds_or32(m, addr, value << sh, p);
 	U32 hi = sel(sh == U32(0u), U32(0u), value >> (U32(32u) - sh));
 	lds_or32(m, addr + 4u, hi, p); // hi == 0 ORs nothing; the image has 4 bytes of slack
+}
+
+// same for a value that cannot straddle a dword: a nibble at a nibble-aligned position, a byte at a byte-aligned one
+WV_FN void lds_put_small(Lds m, const U32& bitpos, const U32& value, const Pred& p)
+{
+	lds_or32(m, (bitpos >> 5) << 2, value << (bitpos & 31u), p);
 }
 
 // all-reduce inside each aligned group of 4 lanes

@@ -1,5 +1,6 @@
 #!/bin/bash
-# VALU/SALU/LDS instructions per block of encode_blocks with phases switched off (diagnostics)
+# VALU/SALU/LDS instructions per block of the fused encoder with phases switched off (diagnostics; frames are wrong)
+# STENOS_DEBUG_PHASES bits: 1 = no LZ attempt, 2 = no emission, 4 = no analysis
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for dbg in 0 1 3 7; do
