@@ -778,7 +778,7 @@ WV_FN uint32_t win_u16(Lds lds, uint32_t addr) { return win_u8(lds, addr) | (win
 // store the four bytes of plane j owned by this element lane into the element-major image
 WV_FN void store_plane_word(Lds lds, uint32_t img, uint32_t T, uint32_t j, const U32& w, const Pred& p)
 {
-	U32 a = U32(img + j) + lane_id() * (4u * T);
+	U32 a = U32(img + j) + lane_id_plain() * (4u * T);
 	lds_st8(lds, a, byte_of(w, 0), p);
 	lds_st8(lds, a + T, byte_of(w, 1), p);
 	lds_st8(lds, a + 2u * T, byte_of(w, 2), p);
@@ -806,7 +806,7 @@ WV_FN U32 chain_compose(const U32& f1, const U32& f2)
 // (seg_mask 63: whole wave, 3: per quad).  Returns the carry-in byte of each lane (0 at a start).
 WV_FN U32 chain_carry(const U32& A, const U32& Bw, uint32_t seg_mask)
 {
-	const U32 lane = lane_id();
+	const U32 lane = lane_id_plain();
 	// the lane's own function: value of its last byte for carry-in 0, and whether the carry goes through
 	U32 last = chain_apply(A, Bw, U32(0u)) >> 24;
 	U32 f = (sel((A & 0xFu) == U32(0xFu), U32(1u), U32(0u)) << 8) | last;
@@ -837,7 +837,7 @@ WV_FN U32 expand_literals(const U32& lits, const U32& f)
 // valid bytes).  Writes rows [0, lines) of plane j into the image.  Returns bytes consumed or DEC_ERROR.
 WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, uint32_t avail, uint32_t lines)
 {
-	const U32 lane = lane_id();
+	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
 	const uint32_t nh = (lines + 1) >> 1;
 	// ---- row view: every group of 16 lanes computes the same 16 rows ----
@@ -942,7 +942,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 // mini-LZ stream -> image.  Returns bytes consumed (after the 253 marker) or DEC_ERROR.
 WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail)
 {
-	const U32 lane = lane_id();
+	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
 	const uint32_t B = lz_width(T);
 	const uint32_t count = 256 * T / B;
@@ -1018,7 +1018,7 @@ WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, 
 // Returns bytes consumed or DEC_ERROR.
 WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail, uint32_t lines, bool full)
 {
-	const U32 lane = lane_id();
+	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
 	const uint32_t hs = header_bytes(T);
 	if (avail <= hs) // src += header_len; src >= end  (block_compress.h:1819-1821)

@@ -17,6 +17,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <memory>
 #include <new>
@@ -528,23 +530,87 @@ unsigned host_threads()
 	return n > 64 ? 64 : n < 1 ? 1 : n;
 }
 
+// Persistent workers (created on first use, joined at unload): a batch of superblocks is a few milliseconds of
+// work, too little to pay for 64 thread creations each time.  One job at a time; the caller works too.
+class WorkerPool {
+	std::vector<std::thread> threads_;
+	std::mutex job_mutex_, m_;
+	std::condition_variable cv_work_, cv_done_;
+	const std::function<void(uint64_t)>* fn_ = nullptr;
+	uint64_t cnt_ = 0, generation_ = 0;
+	std::atomic<uint64_t> next_{ 0 };
+	unsigned busy_ = 0, wanted_ = 0;
+	bool stop_ = false;
+
+	void drain()
+	{
+		for (uint64_t k; (k = next_.fetch_add(1)) < cnt_;)
+			(*fn_)(k);
+	}
+	void loop(unsigned id)
+	{
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(m_);
+		for (;;) {
+			cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
+			if (stop_)
+				return;
+			seen = generation_;
+			if (id >= wanted_)
+				continue;
+			lk.unlock();
+			drain();
+			lk.lock();
+			if (--busy_ == 0)
+				cv_done_.notify_one();
+		}
+	}
+
+public:
+	~WorkerPool()
+	{
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			stop_ = true;
+		}
+		cv_work_.notify_all();
+		for (auto& t : threads_)
+			t.join();
+	}
+	void run(uint64_t cnt, const std::function<void(uint64_t)>& fn)
+	{
+		const unsigned nthreads = host_threads();
+		const unsigned helpers = (unsigned)((cnt < nthreads ? cnt : nthreads) - (cnt ? 1 : 0));
+		std::lock_guard<std::mutex> job(job_mutex_);
+		if (helpers == 0) {
+			for (uint64_t k = 0; k < cnt; ++k)
+				fn(k);
+			return;
+		}
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			while (threads_.size() < helpers) {
+				const unsigned id = (unsigned)threads_.size();
+				threads_.emplace_back([this, id] { loop(id); });
+			}
+			fn_ = &fn;
+			cnt_ = cnt;
+			next_ = 0;
+			wanted_ = helpers;
+			busy_ = helpers;
+			++generation_;
+		}
+		cv_work_.notify_all();
+		drain();
+		std::unique_lock<std::mutex> lk(m_);
+		cv_done_.wait(lk, [&] { return busy_ == 0; });
+	}
+};
+
 void parallel_for(uint64_t cnt, const std::function<void(uint64_t)>& fn)
 {
-	std::atomic<uint64_t> next(0);
-	auto worker = [&]() {
-		for (uint64_t k; (k = next.fetch_add(1)) < cnt;)
-			fn(k);
-	};
-	const unsigned nthreads = host_threads();
-	const unsigned nt = (unsigned)(cnt < nthreads ? cnt : nthreads);
-	if (nt <= 1)
-		return worker();
-	std::vector<std::thread> pool;
-	for (unsigned t = 1; t < nt; ++t)
-		pool.emplace_back(worker);
-	worker();
-	for (auto& t : pool)
-		t.join();
+	static WorkerPool pool;
+	pool.run(cnt, fn);
 }
 
 // Levels >= 2 and bytesoftype 1: the strategy layer of compress_generic_superblock (stenos.cpp:451-604, 617-678).
@@ -743,6 +809,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		return STENOS_ERROR_ALLOC;
 	std::vector<size_t> sizes;
 	std::vector<uint64_t> dslot; // position of a choice-4 superblock in the batch's delta buffer
+	std::vector<size_t> offsets;
 	std::vector<uint8_t> deltas;
 	size_t off = f.header;
 	for (uint64_t s0 = 0; s0 < f.nsb; s0 += batch) {
@@ -750,6 +817,13 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		choice.assign(cnt, 0);
 		parallel_for(cnt, [&](uint64_t k) { choice[k] = decide(s0 + k); });
 		trace.mark("estimates");
+		if (trace.on) {
+			unsigned h[5] = { 0, 0, 0, 0, 0 };
+			for (uint64_t k = 0; k < cnt; ++k)
+				++h[choice[k]];
+			fprintf(stderr, "[stenos]   superblocks %llu: tiny %u, block codec %u, zstd %u, transposed %u, transposed+delta %u\n", (unsigned long long)cnt, h[0], h[1],
+				h[2], h[3], h[4]);
+		}
 		// byte delta of the whole transposed superblock on the GPU for the choice-4 ones (stenos.cpp:646)
 		dslot.assign(cnt, 0);
 		uint64_t nd = 0;
@@ -777,6 +851,24 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 			sizes[k] = emit(s0 + k, choice[k], deltas.data() + dslot[k] * f.sb, scratch.get() + k * ample, ample);
 		});
 		trace.mark("zstd");
+		// Layout in order.  When even the last superblock of the batch finds ample room (the usual case), the
+		// offsets are a plain prefix sum and the copies run on the worker threads.
+		{
+			size_t end = off;
+			bool plain = true;
+			offsets.resize(cnt);
+			for (uint64_t k = 0; k < cnt && plain; ++k) {
+				offsets[k] = end;
+				plain = !is_err(sizes[k]) && dst_size >= end + ample;
+				end += plain ? sizes[k] : 0;
+			}
+			if (plain) {
+				parallel_for(cnt, [&](uint64_t k) { memcpy(h_dst + offsets[k], scratch.get() + k * ample, sizes[k]); });
+				off = end;
+				trace.mark("layout");
+				continue;
+			}
+		}
 		for (uint64_t k = 0; k < cnt; ++k) {
 			if (dst_size < off + 4) // stenos.cpp:427-429
 				return STENOS_ERROR_DST_OVERFLOW;

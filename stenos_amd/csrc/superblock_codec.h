@@ -296,7 +296,7 @@ WV_HD DecLayout make_dec_layout(uint32_t T)
 // bytes at dst.  Returns dsize, or DEC_ERROR on a malformed / truncated stream.
 WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t dsize)
 {
-	const U32 lane = lane_id();
+	const U32 lane = lane_id_plain();
 	const uint32_t bs = 256 * T, hs = header_bytes(T);
 	if (dsize == 0 || csize == 0)
 		return 0;

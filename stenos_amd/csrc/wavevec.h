@@ -109,6 +109,7 @@ WV_FN U32 lane_id()
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)i;
 	return r;
 }
+WV_FN U32 lane_id_plain() { return lane_id(); }
 WV_FN U32 umin(const U32& a, const U32& b)
 {
 	U32 r;
@@ -398,6 +399,13 @@ WV_FN U32 lane_id()
 	// for the int32 encoder, i.e. 4 instead of 8 resident waves per SIMD.  Recomputing them costs next to nothing.
 	asm volatile("" : "+v"(l));
 	__builtin_assume(l < 64u); // lets the compiler drop predicates that are always true for a full wave
+	return l;
+}
+// the lane number the optimiser may reason about (common subexpressions, hoisting): for code that is not short of registers
+WV_FN U32 lane_id_plain()
+{
+	U32 l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	__builtin_assume(l < 64u);
 	return l;
 }
 WV_FN U32 umin(U32 a, U32 b) { return a < b ? a : b; }
