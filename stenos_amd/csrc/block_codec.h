@@ -76,21 +76,37 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 // small helpers
 // ------------------------------------------------------------------------------------------------
 
-// For bytesoftype 4 the lane's four elements (one dword each) stay in registers and the plane words
-// come out of three v_perm_b32 each; other sizes gather the bytes from the LDS copy of the block.
+// For bytesoftype 4, 8, 12, ... the plane words of four consecutive planes [g, g+4) of a lane's four elements come
+// out of one dword per element and three v_perm_b32 per plane; other sizes gather the bytes from the LDS copy.
 struct PlaneRegs {
 	U32 w[4];
 	bool valid;
+	uint32_t g; // first plane held
 };
-WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T)
+WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 {
 	PlaneRegs r;
-	r.valid = T == 4;
+	r.valid = T % 4 == 0;
+	r.g = g;
 	if (r.valid) {
-		U128 e = lds_ld128(lds, U32(in) + lane_id() * 16u);
+		U32 e0, e1, e2, e3; // bytes g..g+3 of the lane's four elements
+		if (T == 4) {
+			U128 e = lds_ld128(lds, U32(in) + lane_id() * 16u);
+			e0 = e.x;
+			e1 = e.y;
+			e2 = e.z;
+			e3 = e.w;
+		}
+		else {
+			U32 a = U32(in + g) + lane_id() * (4u * T);
+			e0 = lds_ld32(lds, a);
+			e1 = lds_ld32(lds, a + T);
+			e2 = lds_ld32(lds, a + 2u * T);
+			e3 = lds_ld32(lds, a + 3u * T);
+		}
 		for (uint32_t j = 0; j < 4; ++j) {
 			const uint32_t s2 = 0x0c0c0000u | ((4u + j) << 8) | j; // [lo.bj, hi.bj, 0, 0]
-			U32 p01 = perm_bytes(e.y, e.x, s2), p23 = perm_bytes(e.w, e.z, s2);
+			U32 p01 = perm_bytes(e1, e0, s2), p23 = perm_bytes(e3, e2, s2);
 			r.w[j] = perm_bytes(p23, p01, 0x05040100u);
 		}
 	}
@@ -99,8 +115,10 @@ WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T)
 // the four bytes of plane j owned by this element lane: elements 4l..4l+3
 WV_FN U32 fetch_plane_word(Lds lds, uint32_t in, uint32_t T, uint32_t j, const PlaneRegs& regs)
 {
-	if (regs.valid)
-		return j == 0 ? regs.w[0] : (j == 1 ? regs.w[1] : (j == 2 ? regs.w[2] : regs.w[3]));
+	if (regs.valid && j - regs.g < 4u) {
+		const uint32_t k = j - regs.g;
+		return k == 0 ? regs.w[0] : (k == 1 ? regs.w[1] : (k == 2 ? regs.w[2] : regs.w[3]));
+	}
 	U32 a = U32(in + j) + lane_id() * (4u * T);
 	U32 b0 = lds_ld8(lds, a);
 	U32 b1 = lds_ld8(lds, a + T);
@@ -226,7 +244,10 @@ WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint3
 {
 	const U32 lane = lane_id();
 	if (regs.valid && np == 4) {
-		analyse_rows_int32(lds, L, regs);
+		if (regs.g == g)
+			analyse_rows_int32(lds, L, regs);
+		else
+			analyse_rows_int32(lds, L, load_plane_regs(lds, L.in, T, g));
 	}
 	else
 	// stage 1: element lanes, one plane at a time -> per-row statistics in L.aux
@@ -397,13 +418,16 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 	// element lanes: row payloads.  Every lane contributes one piece per plane (its 4 raw bytes, its 4
 	// packed values or its rle literals); rle rows add their 4 mask bits.
 	const U32 row = lane >> 2, q = lane & 3u;
+	PlaneRegs cur = regs;
 	for (uint32_t j = 0; j < T; ++j) {
+		if (regs.valid && j % 4 == 0 && j != cur.g)
+			cur = load_plane_regs(lds, L.in, T, j);
 		uint32_t pi = readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
 		uint32_t type = pi & 0xFFu;
 		uint32_t pbase = base + (pi >> 8);
 		if (type == PLANE_SAME)
 			continue;
-		U32 w = fetch_plane_word(lds, L.in, T, j, regs);
+		U32 w = fetch_plane_word(lds, L.in, T, j, cur);
 		if (type == PLANE_RAW) {
 			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, w, pred_all(true));
 			continue;
@@ -711,7 +735,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 // allow_lz mirrors the reference's capacity condition for the LZ attempt (block_compress.h:1214).
 WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
 {
-	const PlaneRegs regs = load_plane_regs(lds, L.in, T);
+	const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
 	if (!(L.dbg & 4u))
 		for (uint32_t g = 0; g < T; g += 4)
 			analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs);
@@ -748,7 +772,7 @@ WV_FN uint32_t encode_partial_lines(Lds lds, const Layout& L, uint32_t T, uint32
 		wave_sync();
 		return 1;
 	}
-	const PlaneRegs regs = load_plane_regs(lds, L.in, T);
+	const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
 	for (uint32_t g = 0; g < T; g += 4)
 		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines, regs);
 	uint32_t pneed;
