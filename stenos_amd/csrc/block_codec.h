@@ -77,7 +77,8 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 // ------------------------------------------------------------------------------------------------
 
 // For bytesoftype 4, 8, 12, ... the plane words of four consecutive planes [g, g+4) of a lane's four elements come
-// out of one dword per element and three v_perm_b32 per plane; other sizes gather the bytes from the LDS copy.
+// out of one dword per element and three v_perm_b32 per plane (bytesoftype 2: both planes out of two dwords);
+// other sizes gather the bytes from the LDS copy.
 struct PlaneRegs {
 	U32 w[4];
 	bool valid;
@@ -86,9 +87,16 @@ struct PlaneRegs {
 WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 {
 	PlaneRegs r;
-	r.valid = T % 4 == 0;
+	r.valid = T % 4 == 0 || T == 2;
 	r.g = g;
-	if (r.valid) {
+	if (T == 2) { // the lane's four 16-bit elements: two dwords, two planes
+		U32 lo, hi;
+		lds_ld64(lds, U32(in) + lane_id() * 8u, lo, hi);
+		r.w[0] = perm_bytes(hi, lo, 0x06040200u);
+		r.w[1] = perm_bytes(hi, lo, 0x07050301u);
+		r.w[2] = r.w[3] = U32(0u);
+	}
+	else if (r.valid) {
 		U32 e0, e1, e2, e3; // bytes g..g+3 of the lane's four elements
 		if (T == 4) {
 			U128 e = lds_ld128(lds, U32(in) + lane_id() * 16u);
@@ -115,7 +123,7 @@ WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 // the four bytes of plane j owned by this element lane: elements 4l..4l+3
 WV_FN U32 fetch_plane_word(Lds lds, uint32_t in, uint32_t T, uint32_t j, const PlaneRegs& regs)
 {
-	if (regs.valid && j - regs.g < 4u) {
+	if (regs.valid && j - regs.g < 4u && j < T) {
 		const uint32_t k = j - regs.g;
 		return k == 0 ? regs.w[0] : (k == 1 ? regs.w[1] : (k == 2 ? regs.w[2] : regs.w[3]));
 	}
