@@ -248,7 +248,10 @@ WV_FN void analyse_rows_int32(Lds lds, const Layout& L, const PlaneRegs& regs)
 
 // Analyse the planes [g, g+np) (np <= 4).  rle: full-block mode (rle + raw override enabled);
 // lines: number of rows that will be emitted (16 for full blocks).
-WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs)
+// praw: when given (bytesoftype <= 4, a single group), the planes' type | size << 8 come back as scalars instead of
+// going through L.plinfo.
+WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs,
+			 uint32_t* praw = nullptr)
 {
 	const U32 lane = lane_id();
 	if (regs.valid && np == 4) {
@@ -337,7 +340,13 @@ WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint3
 	U32 ri = U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u;
 	lds_st32(lds, ri, hdr | (minv << 8) | (poff << 16), valid);
 	lds_st32(lds, ri + 4u, minpos | sel(emit, U32(1u << 12), U32(0u)) | sel(eq, U32(1u << 13), U32(0u)), valid);
-	lds_st32(lds, U32(L.plinfo) + (U32(g) + pl) * 4u, type | (size << 8), valid & (r == U32(0u)));
+	if (praw) {
+		const U32 pinfo = type | (size << 8);
+		for (uint32_t k = 0; k < np; ++k)
+			praw[k] = readlane(pinfo, 16 * k);
+	}
+	else
+		lds_st32(lds, U32(L.plinfo) + (U32(g) + pl) * 4u, type | (size << 8), valid & (r == U32(0u)));
 	wave_sync();
 }
 
@@ -387,13 +396,40 @@ WV_FN uint32_t plane_offsets(Lds lds, const Layout& L, uint32_t T, bool full_blo
 	return full;
 }
 
+// The same on scalars for bytesoftype <= 4: tab[k] = type | size << 8 on entry, type | offset << 8 on return.
+WV_HD uint32_t plane_offsets_small(uint32_t T, bool full_block, uint32_t lines, uint32_t* tab, uint32_t* need)
+{
+	const uint32_t hs = header_bytes(T), nh = (lines + 1) >> 1;
+	uint32_t off = hs, m = 0;
+	for (uint32_t k = 0; k < T; ++k) {
+		const uint32_t type = tab[k] & 0xFFu, size = tab[k] >> 8;
+		uint32_t req;
+		if (full_block)
+			req = type != PLANE_RAW ? off + size + 16u : 0u;
+		else
+			req = type == PLANE_SAME ? off + 1u : off + (size - nh + 8u) + 8u;
+		m = req > m ? req : m;
+		tab[k] = type | (off << 8);
+		off += size;
+	}
+	*need = m > off ? m : off;
+	return off - hs;
+}
+
 // Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
-WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs)
+// tab: the scalar plane table of plane_offsets_small (bytesoftype <= 4) or null (L.plinfo holds it).
+WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs, const uint32_t* tab = nullptr)
 {
 	const U32 lane = lane_id();
 	Lds out = lds + L.out;
 	// plane type nibbles (block_compress.h:1246-1257)
-	{
+	if (tab) {
+		uint32_t nib = 0;
+		for (uint32_t k = 0; k < T; ++k)
+			nib |= (tab[k] & 0xFu) << (4 * k);
+		lds_put_bits(out, U32(base * 8u), U32(nib), lane == U32(0u));
+	}
+	else {
 		Pred valid = lane < U32(T);
 		U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
 		lds_put_small(out, U32(base * 8u) + lane * 4u, pi & 0xFu, valid);
@@ -405,7 +441,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		const Pred valid = pl < U32(np);
 		U32 lo, hi;
 		lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
-		U32 pi = lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
+		U32 pi = tab ? row_select4(tab[0], tab[1], tab[2], tab[3]) : lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
 		U32 type = pi & 0xFFu;
 		U32 pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
 		Pred normal = valid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
@@ -430,7 +466,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 	for (uint32_t j = 0; j < T; ++j) {
 		if (regs.valid && j % 4 == 0 && j != cur.g)
 			cur = load_plane_regs(lds, L.in, T, j);
-		uint32_t pi = readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
+		uint32_t pi = tab ? tab[j] : readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
 		uint32_t type = pi & 0xFFu;
 		uint32_t pbase = base + (pi >> 8);
 		if (type == PLANE_SAME)
@@ -744,11 +780,13 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
 {
 	const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
+	const bool small = T <= 4; // one plane group: its table lives in scalars
+	uint32_t tab[4] = { 0u, 0u, 0u, 0u };
 	if (!(L.dbg & 4u))
 		for (uint32_t g = 0; g < T; g += 4)
-			analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs);
+			analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs, small ? tab : nullptr);
 	uint32_t need;
-	uint32_t full = plane_offsets(lds, L, T, true, 16, &need);
+	uint32_t full = small ? plane_offsets_small(T, true, 16, tab, &need) : plane_offsets(lds, L, T, true, 16, &need);
 	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
 	BlockInfo r;
 	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
@@ -762,7 +800,7 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 	}
 	lds_zero(lds, L.out, out_capacity(T)); // a failed LZ attempt leaves its table there
 	if (!(L.dbg & 2u))
-		emit_planes(lds, L, T, 0, 16, regs);
+		emit_planes(lds, L, T, 0, 16, regs, small ? tab : nullptr);
 	r.size = header_bytes(T) + full;
 	return r;
 }
@@ -781,11 +819,13 @@ WV_FN uint32_t encode_partial_lines(Lds lds, const Layout& L, uint32_t T, uint32
 		return 1;
 	}
 	const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
+	const bool small = T <= 4;
+	uint32_t tab[4] = { 0u, 0u, 0u, 0u };
 	for (uint32_t g = 0; g < T; g += 4)
-		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines, regs);
+		analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, false, lines, regs, small ? tab : nullptr);
 	uint32_t pneed;
-	uint32_t full = plane_offsets(lds, L, T, false, lines, &pneed);
-	emit_planes(lds, L, T, 1, lines, regs);
+	uint32_t full = small ? plane_offsets_small(T, false, lines, tab, &pneed) : plane_offsets(lds, L, T, false, lines, &pneed);
+	emit_planes(lds, L, T, 1, lines, regs, small ? tab : nullptr);
 	if (1 + pneed > *need)
 		*need = 1 + pneed;
 	return 1 + header_bytes(T) + full;

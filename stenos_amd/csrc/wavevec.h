@@ -222,6 +222,13 @@ WV_FN U32 row_shr(const U32& a, uint32_t n, uint32_t fill)
 	return r;
 }
 WV_FN void wave_sync() {}
+// lanes 16k .. 16k+15 receive a_k (four uniform values)
+WV_FN U32 row_select4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = i < 16 ? a0 : (i < 32 ? a1 : (i < 48 ? a2 : a3));
+	return r;
+}
 
 // ---- LDS (byte addressed; 32-bit accesses must be 4-byte aligned unless named *_unaligned) ----
 WV_FN U32 lds_ld8(Lds m, const U32& a)
@@ -474,6 +481,25 @@ WV_FN U32 row_shr(U32 a, uint32_t n, uint32_t fill)
 	if (__builtin_constant_p(fill) && fill == 0)
 		return v; // lanes without a source already read 0
 	return (lane_id() & 15u) >= n ? v : fill;
+}
+// lanes 16k .. 16k+15 receive a_k (four uniform values): four moves under narrowing execution masks, no compare
+WV_FN U32 row_select4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
+{
+	U32 v;
+	uint64_t save;
+	asm volatile("s_mov_b64 %1, exec\n"
+		     "v_mov_b32 %0, %2\n"
+		     "s_and_b64 exec, %1, %6\n"
+		     "v_mov_b32 %0, %3\n"
+		     "s_and_b64 exec, %1, %7\n"
+		     "v_mov_b32 %0, %4\n"
+		     "s_and_b64 exec, %1, %8\n"
+		     "v_mov_b32 %0, %5\n"
+		     "s_mov_b64 exec, %1"
+		     : "=&v"(v), "=&s"(save)
+		     : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(0xFFFFFFFFFFFF0000ull), "s"(0xFFFFFFFF00000000ull), "s"(0xFFFF000000000000ull)
+		     : "scc");
+	return v;
 }
 // orders this wave's LDS accesses (program order is enough for one wave on the hardware; this
 // stops the compiler from moving accesses across the point)

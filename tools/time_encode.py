@@ -25,4 +25,5 @@ for _ in range(reps + 1):
     except Exception as e:  # experimental builds may produce inconsistent frames
         print("error", e)
     ms.append(st.kernel_ms(0))
-print("kernel_ms", " ".join(f"{m:.3f}" for m in ms[1:]))
+v = sorted(ms[1:])
+print(f"{kind} T={T} {gib} GiB [{os.environ.get('STENOS_LIB_PATH', 'tree')}] kernel_ms min {v[0]:.3f} median {v[len(v) // 2]:.3f} max {v[-1]:.3f}")
