@@ -39,6 +39,9 @@ struct Layout {
 };
 
 WV_HD uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+// A plane slot holds the 256 bytes of one plane in plane order (analyse_slots).  Stride 256 + 64: the 16-byte reads of
+// the lanes (row r, slot q) for r = 4k..4k+3, q = 0..3 fall on sixteen different groups of four banks.
+constexpr uint32_t SLOT_STRIDE = 320;
 WV_HD uint32_t lz_width(uint32_t T) { return (T % 8 == 0) ? 8u : 4u; } // lz_compress.h:285-290 for T%4==0
 WV_HD uint32_t header_bytes(uint32_t T) { return (T + 1) >> 1; }
 // a partial block can take 1 + T/2 + T*(8 + 15*17) + (16*T - 1) bytes, more than a full one
@@ -54,7 +57,8 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	L.out = o;
 	o += out_capacity(T);
 	L.rowinfo = o;
-	o += T * 16 * 8;
+	o += (T < 4 ? 4 : T) * 16 * 8; // at least the four plane slots of analyse_slots
+
 	L.plinfo = o;
 	o += align16(T * 4);
 	L.skip = o;
@@ -62,6 +66,8 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	L.aux = o;
 	L.lz = o;
 	uint32_t scratch = 64 * 8;
+	if (T == 2 || T == 4)
+		scratch += 4 * SLOT_STRIDE; // the plane slots of analyse_slots, behind the row statistics
 	if (with_lz && T % 4 == 0) {
 		const uint32_t count = 256 * T / lz_width(T);
 		scratch = count * 8 > scratch ? count * 8 : scratch;
@@ -84,6 +90,59 @@ struct PlaneRegs {
 	bool valid;
 	uint32_t g; // first plane held
 };
+// bytes 0..3 of four consecutive elements (e0..e3, one dword each) -> the four plane words of the lane
+WV_FN void plane_words_from_elements(PlaneRegs& r, const U32& e0, const U32& e1, const U32& e2, const U32& e3)
+{
+	for (uint32_t j = 0; j < 4; ++j) {
+		const uint32_t s2 = 0x0c0c0000u | ((4u + j) << 8) | j; // [lo.bj, hi.bj, 0, 0]
+		U32 p01 = perm_bytes(e1, e0, s2), p23 = perm_bytes(e3, e2, s2);
+		r.w[j] = perm_bytes(p23, p01, 0x05040100u);
+	}
+}
+// the lane's four 16-bit elements (two dwords) -> two plane words
+WV_FN void plane_words_from_int16(PlaneRegs& r, const U32& lo, const U32& hi)
+{
+	r.w[0] = perm_bytes(hi, lo, 0x06040200u);
+	r.w[1] = perm_bytes(hi, lo, 0x07050301u);
+	r.w[2] = r.w[3] = U32(0u);
+}
+// Plane words of a block of bytesoftype 2 or 4 straight from HBM (g 16-byte aligned): the second block of a pair is
+// analysed before it is staged in LDS (superblock_codec.h, encode_run).
+struct RawBlock { // the lane's share of a block of bytesoftype 2 (x, y) or 4 (x, y, z, w): its four elements
+	U128 e;
+};
+WV_FN RawBlock load_raw_block(const uint8_t* g, uint32_t T)
+{
+	RawBlock r;
+	if (T == 2) {
+		gld64(g, lane_id() * 8u, r.e.x, r.e.y);
+		r.e.z = r.e.w = U32(0u);
+	}
+	else
+		r.e = gld128(g, lane_id() * 16u, pred_all(true));
+	return r;
+}
+WV_FN PlaneRegs plane_regs_of(const RawBlock& b, uint32_t T)
+{
+	PlaneRegs r;
+	r.valid = true;
+	r.g = 0;
+	if (T == 2)
+		plane_words_from_int16(r, b.e.x, b.e.y);
+	else
+		plane_words_from_elements(r, b.e.x, b.e.y, b.e.z, b.e.w);
+	return r;
+}
+// the block -> L.in, element major as load_block leaves it
+WV_FN void store_raw_block(Lds lds, uint32_t in, const RawBlock& b, uint32_t T)
+{
+	if (T == 2) {
+		lds_st32(lds, U32(in) + lane_id() * 8u, b.e.x, pred_all(true));
+		lds_st32(lds, U32(in + 4u) + lane_id() * 8u, b.e.y, pred_all(true));
+	}
+	else
+		lds_st128(lds, U32(in) + lane_id() * 16u, b.e, pred_all(true));
+}
 WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 {
 	PlaneRegs r;
@@ -92,9 +151,7 @@ WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 	if (T == 2) { // the lane's four 16-bit elements: two dwords, two planes
 		U32 lo, hi;
 		lds_ld64(lds, U32(in) + lane_id() * 8u, lo, hi);
-		r.w[0] = perm_bytes(hi, lo, 0x06040200u);
-		r.w[1] = perm_bytes(hi, lo, 0x07050301u);
-		r.w[2] = r.w[3] = U32(0u);
+		plane_words_from_int16(r, lo, hi);
 	}
 	else if (r.valid) {
 		U32 e0, e1, e2, e3; // bytes g..g+3 of the lane's four elements
@@ -112,11 +169,7 @@ WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 			e2 = lds_ld32(lds, a + 2u * T);
 			e3 = lds_ld32(lds, a + 3u * T);
 		}
-		for (uint32_t j = 0; j < 4; ++j) {
-			const uint32_t s2 = 0x0c0c0000u | ((4u + j) << 8) | j; // [lo.bj, hi.bj, 0, 0]
-			U32 p01 = perm_bytes(e1, e0, s2), p23 = perm_bytes(e3, e2, s2);
-			r.w[j] = perm_bytes(p23, p01, 0x05040100u);
-		}
+		plane_words_from_elements(r, e0, e1, e2, e3);
 	}
 	return r;
 }
@@ -194,23 +247,11 @@ WV_FN U32 bytes_max16(const U32& e0, const U32& o0, const U32& e1, const U32& o1
 	U32 m = pk_max_u16(pk_max_u16(pk_max_u16(e0, o0), pk_max_u16(e1, o1)), pk_max_u16(pk_max_u16(e2, o2), pk_max_u16(e3, o3)));
 	return umax(m & 0xFFFFu, m >> 16);
 }
-WV_FN void analyse_rows_int32(Lds lds, const Layout& L, const PlaneRegs& regs)
+// Lane 4r+q holds in b[0..3] the 16 bytes of row r of plane (or plane slot) q: statistics of that row -> L.aux.
+WV_FN void row_stats_store(Lds lds, const Layout& L, const U32* b)
 {
 	const U32 lane = lane_id();
 	const U32 q = lane & 3u;
-	// 4 x 4 transpose inside the quad: b[k] = plane-q word of the quad's lane k (elements 4k..4k+3 of the row)
-	U32 b[4];
-	{
-		Pred odd = (q & 1u) == U32(1u), hi = (q & 2u) == U32(2u);
-		U32 r0 = shfl_xor(sel(odd, regs.w[0], regs.w[1]), 1), r1 = shfl_xor(sel(odd, regs.w[2], regs.w[3]), 1);
-		U32 c0 = sel(odd, r0, regs.w[0]), c1 = sel(odd, regs.w[1], r0);
-		U32 c2 = sel(odd, r1, regs.w[2]), c3 = sel(odd, regs.w[3], r1);
-		U32 s0 = shfl_xor(sel(hi, c0, c2), 2), s1 = shfl_xor(sel(hi, c1, c3), 2);
-		b[0] = sel(hi, s0, c0);
-		b[2] = sel(hi, c2, s0);
-		b[1] = sel(hi, s1, c1);
-		b[3] = sel(hi, c3, s1);
-	}
 	// deltas against the previous byte in plane order; before a row comes the last byte of the row above (lane - 4),
 	// before the plane 0 (block_compress.h:399-401)
 	U32 prev = shfl_up(b[3], 4, 0) >> 24;
@@ -242,48 +283,35 @@ WV_FN void analyse_rows_int32(Lds lds, const Layout& L, const PlaneRegs& regs)
 	lds_st32(lds, addr, mn | (mx << 8) | (dmn << 16) | (dmx << 24), pred_all(true));
 	lds_st32(lds, addr + 4u, nrle | (ndrle << 16), pred_all(true));
 }
+WV_FN void analyse_rows_int32(Lds lds, const Layout& L, const PlaneRegs& regs)
+{
+	const U32 q = lane_id() & 3u;
+	// 4 x 4 transpose inside the quad: b[k] = plane-q word of the quad's lane k (elements 4k..4k+3 of the row)
+	U32 b[4];
+	{
+		Pred odd = (q & 1u) == U32(1u), hi = (q & 2u) == U32(2u);
+		U32 r0 = shfl_xor(sel(odd, regs.w[0], regs.w[1]), 1), r1 = shfl_xor(sel(odd, regs.w[2], regs.w[3]), 1);
+		U32 c0 = sel(odd, r0, regs.w[0]), c1 = sel(odd, regs.w[1], r0);
+		U32 c2 = sel(odd, r1, regs.w[2]), c3 = sel(odd, regs.w[3], r1);
+		U32 s0 = shfl_xor(sel(hi, c0, c2), 2), s1 = shfl_xor(sel(hi, c1, c3), 2);
+		b[0] = sel(hi, s0, c0);
+		b[2] = sel(hi, c2, s0);
+		b[1] = sel(hi, s1, c1);
+		b[3] = sel(hi, c3, s1);
+	}
+	row_stats_store(lds, L, b);
+}
 
 // rowinfo entry: lo = hdr | min<<8 | poff<<16 ; hi = minpos | emitmin<<12 | eq<<13
 // plinfo entry : type | size_or_offset<<8
 
-// Analyse the planes [g, g+np) (np <= 4).  rle: full-block mode (rle + raw override enabled);
-// lines: number of rows that will be emitted (16 for full blocks).
-// praw: when given (bytesoftype <= 4, a single group), the planes' type | size << 8 come back as scalars instead of
-// going through L.plinfo.
-WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs,
-			 uint32_t* praw = nullptr)
+// Stage 2 of the analysis, on row lanes: lane 16p + r decides row r of plane g + p from the statistics in L.aux
+// (entry p*16 + r) and leaves the row's header, minimum and offsets in L.rowinfo (entry (g + p)*16 + r).
+WV_FN void analyse_stage2(Lds lds, const Layout& L, uint32_t g, uint32_t np, bool rle, uint32_t lines, uint32_t* praw)
 {
 	const U32 lane = lane_id();
-	if (regs.valid && np == 4) {
-		if (regs.g == g)
-			analyse_rows_int32(lds, L, regs);
-		else
-			analyse_rows_int32(lds, L, load_plane_regs(lds, L.in, T, g));
-	}
-	else
-	// stage 1: element lanes, one plane at a time -> per-row statistics in L.aux
-	for (uint32_t pj = 0; pj < np; ++pj) {
-		U32 w = fetch_plane_word(lds, L.in, T, g + pj, regs);
-		Pred leader = (lane & 3u) == U32(0u);
-		U32 addr = U32(L.aux + pj * 128u) + (lane >> 2) * 8u;
-		const uint32_t first = readlane(w, 0) & 0xFFu;
-		if (!any(w != U32(first * 0x01010101u))) {
-			// all 256 bytes equal (block_compress.h:396, 406, 415-418): statistics of a constant plane, nothing to measure
-			lds_st32(lds, addr, U32((first ^ 0x80u) * 0x0101u), leader);
-			lds_st32(lds, addr + 4u, U32(0u), leader);
-			continue;
-		}
-		PlaneWords p = plane_words(w);
-		U32 cnt = quad_add(popc(p.z1) | (popc(p.z2) << 16));
-		U32 s = p.w ^ 0x80808080u, ds = p.dw ^ 0x80808080u; // signed order (:407-411)
-		U32 mn = quad_min(min4(s)), mx = quad_max(max4(s));
-		U32 dmn = quad_min(min4(ds)), dmx = quad_max(max4(ds));
-		lds_st32(lds, addr, mn | (mx << 8) | (dmn << 16) | (dmx << 24), leader);
-		lds_st32(lds, addr + 4u, cnt, leader);
-	}
-	wave_sync();
+	WV_MARK("analyse_stage2");
 
-	// stage 2: row lanes
 	const U32 r = lane & 15u;
 	const U32 pl = lane >> 4;
 	const Pred valid = pl < U32(np);
@@ -342,13 +370,112 @@ WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint3
 	lds_st32(lds, ri + 4u, minpos | sel(emit, U32(1u << 12), U32(0u)) | sel(eq, U32(1u << 13), U32(0u)), valid);
 	if (praw) {
 		const U32 pinfo = type | (size << 8);
-		for (uint32_t k = 0; k < np; ++k)
-			praw[k] = readlane(pinfo, 16 * k);
+		for (uint32_t k = 0; k < 4; ++k) { // constant indices keep praw in scalar registers
+			const uint32_t v = readlane(pinfo, 16 * k);
+			praw[k] = k < np ? v : praw[k];
+		}
 	}
 	else
 		lds_st32(lds, U32(L.plinfo) + (U32(g) + pl) * 4u, type | (size << 8), valid & (r == U32(0u)));
 	wave_sync();
 }
+
+// Analyse the planes [g, g+np) (np <= 4).  rle: full-block mode (rle + raw override enabled);
+// lines: number of rows that will be emitted (16 for full blocks).
+// praw: when given (bytesoftype <= 4, a single group), the planes' type | size << 8 come back as scalars instead of
+// going through L.plinfo.
+WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs,
+			 uint32_t* praw = nullptr)
+{
+	const U32 lane = lane_id();
+	WV_MARK("analyse_stage1");
+	if (regs.valid && np == 4) {
+		if (regs.g == g)
+			analyse_rows_int32(lds, L, regs);
+		else
+			analyse_rows_int32(lds, L, load_plane_regs(lds, L.in, T, g));
+	}
+	else
+	// stage 1: element lanes, one plane at a time -> per-row statistics in L.aux
+	for (uint32_t pj = 0; pj < np; ++pj) {
+		U32 w = fetch_plane_word(lds, L.in, T, g + pj, regs);
+		Pred leader = (lane & 3u) == U32(0u);
+		U32 addr = U32(L.aux + pj * 128u) + (lane >> 2) * 8u;
+		const uint32_t first = readlane(w, 0) & 0xFFu;
+		if (!any(w != U32(first * 0x01010101u))) {
+			// all 256 bytes equal (block_compress.h:396, 406, 415-418): statistics of a constant plane, nothing to measure
+			lds_st32(lds, addr, U32((first ^ 0x80u) * 0x0101u), leader);
+			lds_st32(lds, addr + 4u, U32(0u), leader);
+			continue;
+		}
+		PlaneWords p = plane_words(w);
+		U32 cnt = quad_add(popc(p.z1) | (popc(p.z2) << 16));
+		U32 s = p.w ^ 0x80808080u, ds = p.dw ^ 0x80808080u; // signed order (:407-411)
+		U32 mn = quad_min(min4(s)), mx = quad_max(max4(s));
+		U32 dmn = quad_min(min4(ds)), dmx = quad_max(max4(ds));
+		lds_st32(lds, addr, mn | (mx << 8) | (dmn << 16) | (dmx << 24), leader);
+		lds_st32(lds, addr + 4u, cnt, leader);
+	}
+	wave_sync();
+	analyse_stage2(lds, L, g, np, rle, lines, praw);
+}
+// ---- plane slots (bytesoftype 2 and 4) ----------------------------------------------------------------------
+// Planes whose 256 bytes are all equal (SAME) need no analysis, and a block of 16-bit elements has only two planes:
+// the row lanes of analyse_stage2 (four planes x 16 rows) would be half idle.  So the planes that do need it are
+// written, in plane order, to up to four "slots" in LDS, which may come from two consecutive blocks; lane 4r + q
+// then reads row r of slot q with one 16-byte load (no cross-lane transpose) and one pass decides all four slots.
+struct SameScan {
+	uint32_t act;   // bit k: plane k is not constant
+	uint32_t nact;  // number of such planes
+	uint32_t first; // first byte of planes 0..3, packed (the byte of a SAME plane)
+};
+WV_FN SameScan scan_same(const PlaneRegs& regs, uint32_t T)
+{
+	SameScan s;
+	s.act = 0;
+	s.nact = 0;
+	s.first = 0;
+	for (uint32_t k = 0; k < T && k < 4; ++k) {
+		const uint32_t f = readlane(regs.w[k], 0) & 0xFFu;
+		s.first |= f << (8 * k);
+		// (block_compress.h:396, 406, 415-418)
+		const uint32_t nz = mask_nonzero(ballot(regs.w[k] != U32(f * 0x01010101u)));
+		s.act |= nz << k;
+		s.nact += nz;
+	}
+	return s;
+}
+WV_HD uint32_t slot_image(const Layout& L, uint32_t s) { return L.aux + 64 * 8 + s * SLOT_STRIDE; }
+// the non-constant planes of a block -> slots slot, slot + 1, ...
+WV_FN void write_slots(Lds lds, const Layout& L, const PlaneRegs& regs, uint32_t T, uint32_t act, uint32_t slot)
+{
+	const U32 lane = lane_id();
+	for (uint32_t k = 0; k < T && k < 4; ++k)
+		if ((act >> k) & 1u) {
+			lds_st32(lds, U32(slot_image(L, slot)) + lane * 4u, regs.w[k], pred_all(true));
+			++slot;
+		}
+}
+// Analyse slots [0, nslots) as full-block planes: row headers -> L.rowinfo entry slot*16 + row, L.plinfo[slot] = type | size << 8.
+WV_FN void analyse_slots(Lds lds, const Layout& L, uint32_t nslots)
+{
+	const U32 lane = lane_id();
+	WV_MARK("analyse_stage1");
+	U128 v = lds_ld128(lds, U32(slot_image(L, 0)) + (lane & 3u) * SLOT_STRIDE + (lane >> 2) * 16u);
+	U32 b[4];
+	b[0] = v.x;
+	b[1] = v.y;
+	b[2] = v.z;
+	b[3] = v.w;
+	row_stats_store(lds, L, b); // slots past nslots hold stale bytes: their results are ignored
+	wave_sync();
+	analyse_stage2(lds, L, 0, nslots, true, 16, nullptr);
+}
+// where emit_planes finds the rows of a block that was analysed in slots
+struct SlotMap {
+	uint32_t first; // first byte of every plane, packed
+	U32 nib;        // lane 0: the plane type nibbles of the block
+};
 
 // What the frame assembly needs to know about an encoded block to reproduce the reference's
 // capacity rules (block_compress.h:1214, 1225, 1241; block_compress_partial :984, 994, 1013):
@@ -418,12 +545,17 @@ WV_HD uint32_t plane_offsets_small(uint32_t T, bool full_block, uint32_t lines, 
 
 // Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
 // tab: the scalar plane table of plane_offsets_small (bytesoftype <= 4) or null (L.plinfo holds it).
-WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs, const uint32_t* tab = nullptr)
+// sm: the block was analysed in slots (tab given): row lanes 16s + r belong to slot s, SAME bytes come from sm->first.
+WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs, const uint32_t* tab = nullptr,
+		       const SlotMap* sm = nullptr)
 {
 	const U32 lane = lane_id();
 	Lds out = lds + L.out;
+	WV_MARK("emit_nibbles");
 	// plane type nibbles (block_compress.h:1246-1257)
-	if (tab) {
+	if (sm)
+		lds_put_bits(out, U32(base * 8u), sm->nib, lane == U32(0u));
+	else if (tab) {
 		uint32_t nib = 0;
 		for (uint32_t k = 0; k < T; ++k)
 			nib |= (tab[k] & 0xFu) << (4 * k);
@@ -435,15 +567,25 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		lds_put_small(out, U32(base * 8u) + lane * 4u, pi & 0xFu, valid);
 	}
 	// row lanes: row-header nibbles, mins, SAME byte
+	WV_MARK("emit_rowlanes");
 	for (uint32_t g = 0; g < T; g += 4) {
 		const uint32_t np = T - g < 4 ? T - g : 4;
 		const U32 r = lane & 15u, pl = lane >> 4;
 		const Pred valid = pl < U32(np);
 		U32 lo, hi;
-		lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
-		U32 pi = tab ? row_select4(tab[0], tab[1], tab[2], tab[3]) : lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
-		U32 type = pi & 0xFFu;
-		U32 pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
+		U32 pi, type, pbase;
+		if (sm) { // lanes 16p + r: plane p, whose rows are those of slot slotof[p] (constant planes: no rows)
+			pi = row_select4(tab[0], tab[1], tab[2], tab[3]); // type | offset << 8 | slot << 24
+			lds_ld64(lds, U32(L.rowinfo) + ((pi >> 24) * 16u + r) * 8u, lo, hi);
+			type = pi & 0xFFu;
+			pbase = U32(base) + ((pi >> 8) & 0xFFFFu);
+		}
+		else {
+			lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
+			pi = tab ? row_select4(tab[0], tab[1], tab[2], tab[3]) : lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
+			type = pi & 0xFFu;
+			pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
+		}
 		Pred normal = valid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
 		Pred act = r < U32(lines);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
@@ -457,26 +599,31 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 				  sel(pl == U32(2u), U32((uint32_t)((eqb >> 32) & 0xFFFF)), U32((uint32_t)(eqb >> 48)))));
 		lds_put_bits(out, (pbase + 8u) * 8u, m16, valid & (type == U32(PLANE_NORMAL_RLE)) & (r == U32(0u)));
 		// SAME: the plane's byte; every row has mx == mn so minv is that byte (:747-750)
-		lds_put_small(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
+		if (!sm)
+			lds_put_small(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
 	}
 	// element lanes: row payloads.  Every lane contributes one piece per plane (its 4 raw bytes, its 4
 	// packed values or its rle literals); rle rows add their 4 mask bits.
 	const U32 row = lane >> 2, q = lane & 3u;
 	PlaneRegs cur = regs;
 	for (uint32_t j = 0; j < T; ++j) {
+		WV_MARK("emit_plane");
 		if (regs.valid && j % 4 == 0 && j != cur.g)
 			cur = load_plane_regs(lds, L.in, T, j);
 		uint32_t pi = tab ? tab[j] : readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
 		uint32_t type = pi & 0xFFu;
-		uint32_t pbase = base + (pi >> 8);
-		if (type == PLANE_SAME)
+		uint32_t pbase = base + ((pi >> 8) & 0xFFFFu);
+		if (type == PLANE_SAME) {
+			if (sm) // (:747-750); without a slot map the row lanes above have written it
+				lds_put_small(out, U32(pbase * 8u), U32((sm->first >> (8 * j)) & 0xFFu), lane == U32(0u));
 			continue;
+		}
 		U32 w = fetch_plane_word(lds, L.in, T, j, cur);
 		if (type == PLANE_RAW) {
 			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, w, pred_all(true));
 			continue;
 		}
-		U32 lo = lds_ld32(lds, U32(L.rowinfo + j * 128u) + row * 8u);
+		U32 lo = lds_ld32(lds, U32(L.rowinfo + (sm ? pi >> 24 : j) * 128u) + row * 8u);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
 		U32 rbase = U32(pbase) + (lo >> 16);
 		Pred act = row < U32(lines);
@@ -508,6 +655,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		}
 		lds_put_bits(out, bitpos, piece, emit);
 	}
+	WV_MARK("emit_end");
 	wave_sync();
 }
 
@@ -520,6 +668,21 @@ WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
 	for (uint32_t o = 0; o < bytes; o += 1024)
 		lds_st128(lds, U32(off + o) + lane * 16u, z, (U32(o) + lane * 16u) < U32(bytes));
 	wave_sync();
+}
+
+// Zeroed image for an encoding of `size` bytes that starts at byte `base` (< 16) of the image.  A block that is
+// appended to a stream (superblock_codec.h, RunStream) starts behind the bytes of its predecessor that did not fill
+// a 16-byte group: they wait, padded with zeros, in the 16 bytes in front of the image and become its first group.
+WV_FN void image_reset(Lds lds, const Layout& L, uint32_t base, uint32_t size)
+{
+	lds_zero(lds, L.out, align16(base + size) + 16u);
+	if (base) {
+		const U32 lane = lane_id();
+		Pred p = lane < U32(4u);
+		U32 a = sel(p, lane, U32(0u)) * 4u;
+		lds_st32(lds, U32(L.out) + a, lds_ld32(lds, U32(L.out - 16u) + a), p);
+		wave_sync();
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,6 +725,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	const uint32_t count = 256 * T / B, nchunks = count / 64;
 	const uint32_t tab = L.out, chain = L.lz, cur = chain + count * 4; // the image is written last: its first KiB serves as the table
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
+	WV_MARK("lz_try");
 
 	const uint32_t gq = quarter / 8 + 1; // first group whose start index exceeds count/4: the early-stop test runs after it
 	const uint32_t nq = 8 * (gq + 1);    // values covered up to and including that group
@@ -740,7 +904,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	}
 
 	// success: write the stream.  Items of a group follow its flag byte.
-	lds_zero(lds, L.out, out_capacity(T)); // the table is no longer needed
+	image_reset(lds, L, base, produced + 1u); // the table is no longer needed
 	Lds out = lds + L.out;
 	lds_put_bits(out, U32(base * 8u), U32(BLOCK_LZ), lane == U32(0u));
 	uint32_t run = base + 1; // byte offset of the next chunk's first group flag
@@ -775,10 +939,11 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	return produced;
 }
 
-// Encode the full block at L.in into the output image (zeroed here).
+// Encode the full block at L.in into the output image (zeroed here), starting at byte `base` (< 16) of the image.
 // allow_lz mirrors the reference's capacity condition for the LZ attempt (block_compress.h:1214).
-WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz)
+WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz, uint32_t base = 0)
 {
+	WV_MARK("block_begin");
 	const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
 	const bool small = T <= 4; // one plane group: its table lives in scalars
 	uint32_t tab[4] = { 0u, 0u, 0u, 0u };
@@ -786,21 +951,98 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 		for (uint32_t g = 0; g < T; g += 4)
 			analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs, small ? tab : nullptr);
 	uint32_t need;
+	WV_MARK("plane_offsets");
 	uint32_t full = small ? plane_offsets_small(T, true, 16, tab, &need) : plane_offsets(lds, L, T, true, 16, &need);
 	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
 	BlockInfo r;
 	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
 	if (allow_lz && eligible && !(L.dbg & 1u)) {
-		uint32_t n = lz_try(lds, L, T, full, 0);
+		uint32_t n = lz_try(lds, L, T, full, base);
 		if (n) {
 			r.size = n + 1;
 			r.info |= 1u << 31;
 			return r;
 		}
 	}
-	lds_zero(lds, L.out, out_capacity(T)); // a failed LZ attempt leaves its table there
+	WV_MARK("image_reset");
+	image_reset(lds, L, base, header_bytes(T) + full); // a failed LZ attempt leaves its table there
 	if (!(L.dbg & 2u))
-		emit_planes(lds, L, T, 0, 16, regs, small ? tab : nullptr);
+		emit_planes(lds, L, T, base, 16, regs, small ? tab : nullptr);
+	r.size = header_bytes(T) + full;
+	return r;
+}
+
+// The same for a block of bytesoftype 2 or 4 whose non-constant planes have been analysed in slots slot_lo, slot_lo + 1, ...
+// (L.plinfo[slot] = type | size << 8); L.in holds the block.
+WV_FN BlockInfo finish_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz, uint32_t base, const PlaneRegs& regs, const SameScan& sc,
+			     uint32_t slot_lo)
+{
+	uint32_t tab[4] = { 0u, 0u, 0u, 0u }; // per plane: type | offset << 8 | slot << 24
+	SlotMap sm;
+	uint32_t full, need;
+	if (T <= 2) {
+		// two planes: scalars are the shorter way
+		const U32 pinfo = lds_ld32(lds, U32(L.plinfo) + (lane_id() & 3u) * 4u); // lane q: the entry of slot q
+		uint32_t slot = slot_lo, slots[2] = { 0u, 0u };
+		for (uint32_t k = 0; k < T; ++k) {
+			if ((sc.act >> k) & 1u) {
+				tab[k] = readlane(pinfo, slot);
+				slots[k] = slot;
+				++slot;
+			}
+			else
+				tab[k] = PLANE_SAME | (1u << 8);
+		}
+		WV_MARK("plane_offsets");
+		uint32_t nib = 0;
+		for (uint32_t k = 0; k < T; ++k)
+			nib |= (tab[k] & 0xFu) << (4 * k);
+		full = plane_offsets_small(T, true, 16, tab, &need);
+		for (uint32_t k = 0; k < T; ++k)
+			tab[k] |= slots[k] << 24;
+		sm.first = sc.first;
+		sm.nib = U32(nib);
+	}
+	else {
+		// The plane table is built on lanes (lane k of every quad: plane k) and only its results become scalars: scalar
+		// instructions cost an issue slot like vector ones, and tables indexed by run-time values would leave the registers.
+		const U32 lane = lane_id();
+		const U32 k = lane & 3u;
+		const Pred inblock = k < U32(T);
+		const Pred active = inblock & (((U32(sc.act) >> k) & 1u) == U32(1u));
+		const U32 slotv = U32(slot_lo) + popc(U32(sc.act) & ((U32(1u) << k) - 1u)); // slots follow the plane order
+		U32 pinfo = lds_ld32(lds, U32(L.plinfo) + sel(active, slotv, U32(0u)) * 4u);
+		pinfo = sel(active, pinfo, sel(inblock, U32(PLANE_SAME | (1u << 8)), U32(0u)));
+		const U32 type = pinfo & 0xFFu, size = pinfo >> 8;
+		WV_MARK("plane_offsets");
+		U32 incl = size + sel(k >= U32(1u), row_shr(size, 1, 0), U32(0u)); // prefix sums inside the quad
+		incl = incl + sel(k >= U32(2u), row_shr(incl, 2, 0), U32(0u));
+		const uint32_t hs = header_bytes(T);
+		const U32 off = U32(hs) + incl - size;
+		full = readlane(incl, 3);
+		// capacity the plane loop needs (block_compress.h:1241): see plane_offsets
+		const uint32_t m = readlane(quad_max(sel(inblock & (type != U32(PLANE_RAW)), off + size + 16u, U32(0u))), 0);
+		need = m > hs + full ? m : hs + full;
+		const U32 tabv = type | (off << 8) | (sel(active, slotv, U32(0u)) << 24);
+		for (uint32_t j = 0; j < 4; ++j)
+			tab[j] = readlane(tabv, j);
+		sm.first = sc.first;
+		sm.nib = quad_add(sel(inblock, type << (k << 2), U32(0u)));
+	}
+	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
+	BlockInfo r;
+	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
+	if (allow_lz && eligible) {
+		uint32_t n = lz_try(lds, L, T, full, base);
+		if (n) {
+			r.size = n + 1;
+			r.info |= 1u << 31;
+			return r;
+		}
+	}
+	WV_MARK("image_reset");
+	image_reset(lds, L, base, header_bytes(T) + full);
+	emit_planes(lds, L, T, base, 16, regs, tab, &sm);
 	r.size = header_bytes(T) + full;
 	return r;
 }

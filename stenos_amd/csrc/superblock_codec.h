@@ -111,59 +111,32 @@ WV_FN BlockInfo encode_block_job(Lds lds, const Layout& L, uint32_t T, const uin
 // ---- a run of consecutive blocks -> one contiguous byte stream ------------------------------------
 //
 // A wavefront that encodes consecutive blocks appends their images to a contiguous stream in HBM (its share
-// of a superblock payload).  The stream is written in aligned 16-byte groups only: bytes of a block that do
-// not fill a group wait in the 16 bytes in front of the LDS image (Layout::out - 16 .. out) for the next one.
+// of a superblock payload).  The stream is written in aligned 16-byte groups only.  The bytes of a block that do
+// not fill a group wait, padded with zeros, in the 16 bytes in front of the LDS image (Layout::out - 16 .. out);
+// the next block is encoded behind them (image offset pos % 16, block_codec.h image_reset), so every append is a
+// plain aligned copy.
 struct RunStream {
 	uint8_t* base; // 16-byte aligned
 	uint32_t pos;  // bytes appended so far; the last pos % 16 of them are still in LDS
 };
 
-// append the n image bytes at LDS offset `out`
+// append the n bytes that were encoded at image offset rs.pos % 16 (the image starts with the waiting bytes)
 WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 {
 	const U32 lane = lane_id();
 	const uint32_t r = rs.pos & 15u;
 	const uint32_t groups = (r + n) >> 4;
 	uint8_t* g = rs.base + (rs.pos - r);
-	if (r == 0) {
-		for (uint32_t o = 0; o < groups; o += 64) {
-			U32 k = U32(o) + lane;
-			Pred p = k < U32(groups);
-			gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
-		}
+	for (uint32_t o = 0; o < groups; o += 64) {
+		U32 k = U32(o) + lane;
+		Pred p = k < U32(groups);
+		gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
 	}
-	else {
-		const uint32_t start = out - r;       // LDS offset of the first byte that is not in HBM yet
-		const uint32_t a0 = start & ~3u;      // five aligned dwords hold the 16 bytes of a group
-		const uint32_t sh = (start & 3u) * 8u;
-		for (uint32_t o = 0; o < groups; o += 64) {
-			U32 k = U32(o) + lane;
-			Pred p = k < U32(groups);
-			U32 la = U32(a0) + sel(p, k, U32(0u)) * 16u;
-			U32 d0 = lds_ld32(lds, la), d1 = lds_ld32(lds, la + 4u), d2 = lds_ld32(lds, la + 8u), d3 = lds_ld32(lds, la + 12u);
-			U128 v;
-			if (sh) {
-				U32 d4 = lds_ld32(lds, la + 16u);
-				v.x = (d0 >> U32(sh)) | (d1 << U32(32u - sh));
-				v.y = (d1 >> U32(sh)) | (d2 << U32(32u - sh));
-				v.z = (d2 >> U32(sh)) | (d3 << U32(32u - sh));
-				v.w = (d3 >> U32(sh)) | (d4 << U32(32u - sh));
-			}
-			else {
-				v.x = d0;
-				v.y = d1;
-				v.z = d2;
-				v.w = d3;
-			}
-			gst128(g, k * 16u, v, p);
-		}
-	}
-	// the bytes behind the last full group move in front of the image
-	const uint32_t r2 = (r + n) & 15u;
-	Pred t = lane < U32(r2);
-	U32 b = lds_ld8(lds, U32(out + n - r2) + sel(t, lane, U32(0u)));
-	wave_sync();
-	lds_st8(lds, U32(out - r2) + lane, b, t);
+	// the group behind them (its bytes past the encoding are zero) waits in front of the image
+	Pred t = lane < U32(4u);
+	U32 a = sel(t, lane, U32(0u)) * 4u;
+	U32 v = lds_ld32(lds, U32(out + groups * 16u) + a);
+	lds_st32(lds, U32(out - 16u) + a, v, t);
 	wave_sync();
 	rs.pos += n;
 }
@@ -172,7 +145,7 @@ WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 	const U32 lane = lane_id();
 	const uint32_t r = rs.pos & 15u;
 	Pred t = lane < U32(r);
-	gst8(rs.base + (rs.pos - r), lane, lds_ld8(lds, U32(out - r) + sel(t, lane, U32(0u))), t);
+	gst8(rs.base + (rs.pos - r), lane, lds_ld8(lds, U32(out - 16u) + sel(t, lane, U32(0u))), t);
 }
 
 // `nblocks` full blocks at src -> their encodings, back to back, at stage (16-byte aligned, room for
@@ -183,10 +156,77 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 	RunStream rs;
 	rs.base = stage;
 	rs.pos = 0;
+	if (T == 2 || T == 4) {
+		// Planes in slots (block_codec.h, analyse_slots): a block whose non-constant planes leave two slots free is
+		// analysed together with its successor when that one fits into the rest.
+		const uint32_t bs = 256 * T;
+		uint32_t i = 0;
+		while (i < nblocks) {
+			const uint8_t* a = src + (uint64_t)i * bs;
+			const uint8_t* b = a + bs;
+			WV_MARK("load_block");
+			// both blocks are requested at once, straight into registers; when the second one is not paired after all,
+			// its load has at least brought it closer for the next round
+			const bool fast = (((uintptr_t)a) & 15u) == 0;
+			const bool has_b = fast && i + 1 < nblocks;
+			PlaneRegs ra;
+			RawBlock eb;
+			if (fast) {
+				const RawBlock ea = load_raw_block(a, T);
+				if (has_b)
+					eb = load_raw_block(b, T);
+				store_raw_block(lds, L.in, ea, T);
+				ra = plane_regs_of(ea, T);
+			}
+			else {
+				load_block(lds, L.in, a, bs);
+				wave_sync();
+				ra = load_plane_regs(lds, L.in, T, 0);
+			}
+			WV_MARK("block_begin");
+			const SameScan sa = scan_same(ra, T);
+			write_slots(lds, L, ra, T, sa.act, 0);
+			SameScan sb = sa;
+			bool pair = false;
+			if (has_b && sa.nact <= 2) {
+				const PlaneRegs rb = plane_regs_of(eb, T);
+				sb = scan_same(rb, T);
+				if (sa.nact + sb.nact <= 4) {
+					write_slots(lds, L, rb, T, sb.act, sa.nact);
+					pair = true;
+				}
+			}
+			const uint32_t nslots = sa.nact + (pair ? sb.nact : 0u);
+			wave_sync();
+			if (nslots)
+				analyse_slots(lds, L, nslots);
+			// the blocks of the batch, one after the other; the plane words are fetched again rather than kept in
+			// registers across the analysis (8 waves per SIMD leave 64 of them)
+			const uint32_t nblk = pair ? 2u : 1u;
+			for (uint32_t k = 0; k < nblk; ++k) {
+				if (k) {
+					load_block(lds, L.in, b, bs);
+					wave_sync();
+				}
+				const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
+				SameScan sc;
+				sc.act = k ? sb.act : sa.act;
+				sc.nact = k ? sb.nact : sa.nact;
+				sc.first = k ? sb.first : sa.first;
+				const BlockInfo r = finish_block(lds, L, T, true, rs.pos & 15u, regs, sc, k ? sa.nact : 0u);
+				WV_MARK("stream_append");
+				stream_append(rs, lds, L.out, r.size);
+				WV_MARK("block_end");
+			}
+			i += pair ? 2u : 1u;
+		}
+		stream_flush(rs, lds, L.out);
+		return rs.pos;
+	}
 	for (uint32_t i = 0; i < nblocks; ++i) {
 		load_block(lds, L.in, src + (uint64_t)i * (256 * T), 256 * T);
 		wave_sync();
-		BlockInfo r = encode_full_block(lds, L, T, true);
+		BlockInfo r = encode_full_block(lds, L, T, true, rs.pos & 15u);
 		stream_append(rs, lds, L.out, r.size);
 	}
 	stream_flush(rs, lds, L.out);

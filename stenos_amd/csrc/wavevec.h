@@ -21,6 +21,7 @@
 #include <string.h>
 #define WV_FN static inline
 #define WV_HD static inline
+#define WV_MARK(name)
 namespace wv {
 constexpr int WAVE = 64;
 
@@ -186,6 +187,8 @@ WV_FN uint64_t ballot(const Pred& p)
 	return m;
 }
 WV_FN uint32_t readlane(const U32& a, uint32_t lane) { return a.l[lane & 63]; }
+// 1 when the lane mask is not empty, else 0
+WV_FN uint32_t mask_nonzero(uint64_t m) { return m ? 1u : 0u; }
 // lane i reads a[src[i] & 63]
 WV_FN U32 shfl(const U32& a, const U32& src)
 {
@@ -316,6 +319,13 @@ WV_FN U32 gld32(const uint8_t* g, const U32& off, const Pred& p) // off multiple
 		if (p.l[i]) memcpy(&r.l[i], g + off.l[i], 4);
 	return r;
 }
+WV_FN void gld64(const uint8_t* g, const U32& off, U32& lo, U32& hi) // 8-byte aligned, all lanes
+{
+	for (int i = 0; i < WAVE; ++i) {
+		memcpy(&lo.l[i], g + off.l[i], 4);
+		memcpy(&hi.l[i], g + off.l[i] + 4, 4);
+	}
+}
 WV_FN U128 gld128(const uint8_t* g, const U32& off, const Pred& p) // 16-byte aligned
 {
 	U128 r;
@@ -390,6 +400,8 @@ WV_FN void lds_st128(Lds m, const U32& a, const U128& v, const Pred& p)
 #include <hip/hip_runtime.h>
 #define WV_FN static __device__ __forceinline__
 #define WV_HD static __host__ __device__ __forceinline__
+// a comment line in the generated ISA (tools/isa_regions.py counts the instructions between marks); no code
+#define WV_MARK(name) asm volatile("; MARK " name)
 namespace wv {
 constexpr int WAVE = 64;
 typedef uint32_t U32;
@@ -426,6 +438,14 @@ WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __ballot(p); }
 WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }
+// 1 when the lane mask is not empty, else 0 -- as an integer in a scalar register (a C++ bool would be kept as a
+// lane mask and turned into a number through vector registers)
+WV_FN uint32_t mask_nonzero(uint64_t m)
+{
+	uint32_t r;
+	asm("s_bcnt1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, 1" : "=s"(r) : "s"(m) : "scc");
+	return r;
+}
 WV_FN U32 shfl(U32 a, U32 src) { return (U32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)a); }
 // generic forms (LDS crossbar); the shapes the codec uses most have DPP forms below
 WV_FN U32 shfl_up_any(U32 a, uint32_t n, uint32_t fill)
@@ -548,6 +568,12 @@ struct U128 {
 };
 WV_FN U32 gld8(const uint8_t* g, U32 off, Pred p) { return p ? (U32)g[off] : 0u; }
 WV_FN U32 gld32(const uint8_t* g, U32 off, Pred p) { return p ? *(const uint32_t*)(g + off) : 0u; }
+WV_FN void gld64(const uint8_t* g, U32 off, U32& lo, U32& hi)
+{
+	uint2 v = *(const uint2*)(g + off);
+	lo = v.x;
+	hi = v.y;
+}
 WV_FN U128 gld128(const uint8_t* g, U32 off, Pred p)
 {
 	U128 r = { 0u, 0u, 0u, 0u };

@@ -50,7 +50,8 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     kinds: sorted_i32 (README example, T=4), rand (full entropy), rand12 (u & 0xFFF, T=4),
     same, sorted (lexicographically sorted random elements, signed bytes as std::array<char,N>),
     walk (x += u%17 - 8), dict16 (16-entry dictionary), runs (runs of 7), burst, ramp,
-    sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal).
+    sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal),
+    mixed (per block and plane: constant / narrow / random / walk / runs).
     """
     if n == 0:
         return np.zeros(0, dtype=np.uint8)
@@ -90,6 +91,18 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
         a[burst] = r[burst] & 0x3F
         a += ((np.arange(n) // 64) % 3).astype(np.uint8)[:, None]
         return a.reshape(-1)
+    if kind == "mixed":
+        # every plane of every 256-element block has a style of its own (constant, narrow, random, walk, runs):
+        # neighbouring blocks differ in how many planes are constant
+        nb = (n + 255) // 256
+        style = (splitmix64(seed + 7, nb * T) % np.uint64(6)).astype(np.int64).reshape(nb, 1, T)
+        r = generate("rand", T, nb * 256, seed + 3).reshape(nb, 256, T)
+        const = np.broadcast_to(r[:, :1, :], r.shape)
+        narrow = (r & 0x0F) + const
+        walk = np.cumsum((r % 5).astype(np.int64) - 2, axis=1).astype(np.uint8) + const
+        runs = np.repeat(r[:, ::16, :], 16, axis=1)
+        a = np.where(style <= 1, const, np.where(style == 2, narrow, np.where(style == 3, r, np.where(style == 4, walk, runs))))
+        return np.ascontiguousarray(a.astype(np.uint8).reshape(nb * 256, T)[:n]).reshape(-1)
     if kind == "sine":
         x = np.sin(np.arange(n, dtype=np.float64) * 0.001)
         if T == 8:
