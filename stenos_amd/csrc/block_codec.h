@@ -545,7 +545,8 @@ WV_HD uint32_t plane_offsets_small(uint32_t T, bool full_block, uint32_t lines, 
 
 // Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
 // tab: the scalar plane table of plane_offsets_small (bytesoftype <= 4) or null (L.plinfo holds it).
-// sm: the block was analysed in slots (tab given): row lanes 16s + r belong to slot s, SAME bytes come from sm->first.
+// sm: the block was analysed in slots (tab given, entries type | offset << 8 | slot << 24): the rows and the plane words
+// of a plane are those of its slot (regs is not used), SAME bytes come from sm->first.
 WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs, const uint32_t* tab = nullptr,
 		       const SlotMap* sm = nullptr)
 {
@@ -618,7 +619,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 				lds_put_small(out, U32(pbase * 8u), U32((sm->first >> (8 * j)) & 0xFFu), lane == U32(0u));
 			continue;
 		}
-		U32 w = fetch_plane_word(lds, L.in, T, j, cur);
+		U32 w = sm ? lds_ld32(lds, U32(slot_image(L, pi >> 24)) + lane * 4u) : fetch_plane_word(lds, L.in, T, j, cur);
 		if (type == PLANE_RAW) {
 			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, w, pred_all(true));
 			continue;
@@ -718,7 +719,8 @@ WV_FN U32 lz_hash(const LzVal& v, uint32_t B)
 // Try to encode the block held at L.in with the mini-LZ.  Returns the number of bytes produced
 // (after the 253 marker) or 0 when the reference would give up.  On success the stream has been
 // written to the zeroed output image at byte base+1 and the marker at base.
-WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base)
+// *scratch_used (optional) is set once the attempt gets past its first rejection test and starts using L.lz.
+WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base, bool* scratch_used = nullptr)
 {
 	const U32 lane = lane_id();
 	const uint32_t B = lz_width(T);
@@ -753,6 +755,8 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		if (lower > max_size || (double)lower > (double)max_size * 0.4)
 			return 0;
 	}
+	if (scratch_used)
+		*scratch_used = true;
 
 	{
 		// Second rejection test, for data whose values hardly repeat (floats, noise): a value can only match
@@ -968,81 +972,6 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 	image_reset(lds, L, base, header_bytes(T) + full); // a failed LZ attempt leaves its table there
 	if (!(L.dbg & 2u))
 		emit_planes(lds, L, T, base, 16, regs, small ? tab : nullptr);
-	r.size = header_bytes(T) + full;
-	return r;
-}
-
-// The same for a block of bytesoftype 2 or 4 whose non-constant planes have been analysed in slots slot_lo, slot_lo + 1, ...
-// (L.plinfo[slot] = type | size << 8); L.in holds the block.
-WV_FN BlockInfo finish_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz, uint32_t base, const PlaneRegs& regs, const SameScan& sc,
-			     uint32_t slot_lo)
-{
-	uint32_t tab[4] = { 0u, 0u, 0u, 0u }; // per plane: type | offset << 8 | slot << 24
-	SlotMap sm;
-	uint32_t full, need;
-	if (T <= 2) {
-		// two planes: scalars are the shorter way
-		const U32 pinfo = lds_ld32(lds, U32(L.plinfo) + (lane_id() & 3u) * 4u); // lane q: the entry of slot q
-		uint32_t slot = slot_lo, slots[2] = { 0u, 0u };
-		for (uint32_t k = 0; k < T; ++k) {
-			if ((sc.act >> k) & 1u) {
-				tab[k] = readlane(pinfo, slot);
-				slots[k] = slot;
-				++slot;
-			}
-			else
-				tab[k] = PLANE_SAME | (1u << 8);
-		}
-		WV_MARK("plane_offsets");
-		uint32_t nib = 0;
-		for (uint32_t k = 0; k < T; ++k)
-			nib |= (tab[k] & 0xFu) << (4 * k);
-		full = plane_offsets_small(T, true, 16, tab, &need);
-		for (uint32_t k = 0; k < T; ++k)
-			tab[k] |= slots[k] << 24;
-		sm.first = sc.first;
-		sm.nib = U32(nib);
-	}
-	else {
-		// The plane table is built on lanes (lane k of every quad: plane k) and only its results become scalars: scalar
-		// instructions cost an issue slot like vector ones, and tables indexed by run-time values would leave the registers.
-		const U32 lane = lane_id();
-		const U32 k = lane & 3u;
-		const Pred inblock = k < U32(T);
-		const Pred active = inblock & (((U32(sc.act) >> k) & 1u) == U32(1u));
-		const U32 slotv = U32(slot_lo) + popc(U32(sc.act) & ((U32(1u) << k) - 1u)); // slots follow the plane order
-		U32 pinfo = lds_ld32(lds, U32(L.plinfo) + sel(active, slotv, U32(0u)) * 4u);
-		pinfo = sel(active, pinfo, sel(inblock, U32(PLANE_SAME | (1u << 8)), U32(0u)));
-		const U32 type = pinfo & 0xFFu, size = pinfo >> 8;
-		WV_MARK("plane_offsets");
-		U32 incl = size + sel(k >= U32(1u), row_shr(size, 1, 0), U32(0u)); // prefix sums inside the quad
-		incl = incl + sel(k >= U32(2u), row_shr(incl, 2, 0), U32(0u));
-		const uint32_t hs = header_bytes(T);
-		const U32 off = U32(hs) + incl - size;
-		full = readlane(incl, 3);
-		// capacity the plane loop needs (block_compress.h:1241): see plane_offsets
-		const uint32_t m = readlane(quad_max(sel(inblock & (type != U32(PLANE_RAW)), off + size + 16u, U32(0u))), 0);
-		need = m > hs + full ? m : hs + full;
-		const U32 tabv = type | (off << 8) | (sel(active, slotv, U32(0u)) << 24);
-		for (uint32_t j = 0; j < 4; ++j)
-			tab[j] = readlane(tabv, j);
-		sm.first = sc.first;
-		sm.nib = quad_add(sel(inblock, type << (k << 2), U32(0u)));
-	}
-	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
-	BlockInfo r;
-	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
-	if (allow_lz && eligible) {
-		uint32_t n = lz_try(lds, L, T, full, base);
-		if (n) {
-			r.size = n + 1;
-			r.info |= 1u << 31;
-			return r;
-		}
-	}
-	WV_MARK("image_reset");
-	image_reset(lds, L, base, header_bytes(T) + full);
-	emit_planes(lds, L, T, base, 16, regs, tab, &sm);
 	r.size = header_bytes(T) + full;
 	return r;
 }
