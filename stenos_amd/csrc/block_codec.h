@@ -45,7 +45,8 @@ constexpr uint32_t SLOT_STRIDE = 320;
 WV_HD uint32_t lz_width(uint32_t T) { return (T % 8 == 0) ? 8u : 4u; } // lz_compress.h:285-290 for T%4==0
 WV_HD uint32_t header_bytes(uint32_t T) { return (T + 1) >> 1; }
 // a partial block can take 1 + T/2 + T*(8 + 15*17) + (16*T - 1) bytes, more than a full one
-WV_HD uint32_t out_capacity(uint32_t T) { return align16(280 * T + header_bytes(T) + 40); }
+// bytesoftype 2: two full blocks of a pair are written into the image together (emit_batch)
+WV_HD uint32_t out_capacity(uint32_t T) { return T == 2 ? 1088u : align16(280 * T + header_bytes(T) + 40); }
 
 WV_HD Layout make_layout(uint32_t T, bool with_lz)
 {
@@ -60,7 +61,7 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	o += (T < 4 ? 4 : T) * 16 * 8; // at least the four plane slots of analyse_slots
 
 	L.plinfo = o;
-	o += align16(T * 4);
+	o += align16(T * 4) + (T <= 4 ? 16 : 0); // bytesoftype 2 and 4: + the slot table of emit_batch
 	L.skip = o;
 	o += 32;
 	L.aux = o;
@@ -660,6 +661,135 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 	wave_sync();
 }
 
+// ---- blocks analysed in slots: plane table and emission on lanes --------------------------------------------
+// A batch is one block or two consecutive ones whose non-constant planes fill slots 0 .. nslots-1 (block 0 first).
+// Lane 4*blk + k of every group of eight lanes stands for plane k of block blk.
+struct BatchPlan {
+	U32 type, off, slot; // plane type, offset of the plane in its block's encoding, slot of a non-constant plane
+	Pred inblock, active;
+	uint32_t full[2];    // sum of the plane sizes of each block (block_compress.h:1189-1207)
+};
+WV_FN BatchPlan plan_batch(Lds lds, const Layout& L, uint32_t T, uint32_t act0, uint32_t act1, uint32_t nblk)
+{
+	BatchPlan P;
+	const U32 lane = lane_id();
+	const U32 k = lane & 3u;
+	const Pred second = ((lane >> 2) & 1u) == U32(1u);
+	const U32 actv = sel(second, U32(act1), U32(act0));
+	P.inblock = (k < U32(T)) & (sel(second, U32(1u), U32(0u)) < U32(nblk));
+	P.active = P.inblock & (((actv >> k) & 1u) == U32(1u));
+	P.slot = popc(actv & ((U32(1u) << k) - 1u)) + sel(second, popc(U32(act0)), U32(0u)); // slots follow block and plane order
+	U32 pinfo = lds_ld32(lds, U32(L.plinfo) + sel(P.active, P.slot, U32(0u)) * 4u);
+	pinfo = sel(P.active, pinfo, sel(P.inblock, U32(PLANE_SAME | (1u << 8)), U32(0u)));
+	P.type = pinfo & 0xFFu;
+	const U32 size = pinfo >> 8;
+	U32 incl = size + sel(k >= U32(1u), row_shr(size, 1, 0), U32(0u)); // prefix sums inside the quad
+	incl = incl + sel(k >= U32(2u), row_shr(incl, 2, 0), U32(0u));
+	P.off = U32(header_bytes(T)) + incl - size;
+	P.full[0] = readlane(incl, 3);
+	P.full[1] = readlane(incl, 7);
+	return P;
+}
+
+// four values of at most `bits` bits, one per byte of x -> 4*bits bits
+WV_FN U32 pack4(const U32& x, const U32& bits)
+{
+	U32 t = (x & 0x00FF00FFu) | (((x >> 8) & 0x00FF00FFu) << bits);
+	return (t & 0xFFFFu) | ((t >> 16) << (bits + bits));
+}
+
+// Write the blocks of a batch named by `mask` (bit blk) into the zeroed image, block blk starting at byte base[blk]:
+// type nibbles and SAME bytes by the plane lanes, then lane 16s + r writes row r of slot s -- row header, minimum and
+// payload in one pass over all slots (block_compress.h:739-806, 1246-1257).  nslots0: slots of block 0, nslots: of both.
+WV_FN void emit_batch(Lds lds, const Layout& L, uint32_t T, const BatchPlan& P, uint32_t first0, uint32_t first1, uint32_t mask, uint32_t base0,
+		      uint32_t base1, uint32_t nslots0, uint32_t nslots)
+{
+	const U32 lane = lane_id();
+	Lds out = lds + L.out;
+	WV_MARK("emit_nibbles");
+	{
+		const U32 k = lane & 3u;
+		const Pred second = ((lane >> 2) & 1u) == U32(1u);
+		const Pred pending = ((U32(mask) >> sel(second, U32(1u), U32(0u))) & 1u) == U32(1u);
+		const Pred mine = P.inblock & pending & (lane < U32(8u));
+		const U32 bbase = sel(second, U32(base1), U32(base0));
+		const U32 nib = quad_add(sel(P.inblock, P.type << (k << 2), U32(0u)));
+		lds_put_bits(out, bbase * 8u, nib, mine & (k == U32(0u)));
+		const U32 byte = (sel(second, U32(first1), U32(first0)) >> (k << 3)) & 0xFFu; // (:747-750)
+		lds_put_small(out, (bbase + P.off) * 8u, byte, mine & (P.type == U32(PLANE_SAME)));
+		lds_st32(lds, U32(L.plinfo + 16u) + sel(P.active, P.slot, U32(0u)) * 4u, P.type | ((bbase + P.off) << 8), mine & P.active);
+		wave_sync();
+	}
+	WV_MARK("emit_rowlanes");
+	const U32 s = lane >> 4, r = lane & 15u;
+	const U32 sinfo = lds_ld32(lds, U32(L.plinfo + 16u) + s * 4u);
+	const Pred svalid = sel(s < U32(nslots0), U32(mask & 1u), sel(s < U32(nslots), U32((mask >> 1) & 1u), U32(0u))) == U32(1u);
+	const U32 type = sinfo & 0xFFu, pbase = sinfo >> 8;
+	const Pred normal = svalid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
+	const Pred israw = svalid & (type == U32(PLANE_RAW));
+	U32 lo, hi;
+	lds_ld64(lds, U32(L.rowinfo) + lane * 8u, lo, hi);
+	const U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
+	lds_put_small(out, pbase * 8u + r * 4u, hdr, normal); // (:768-779, 758-762)
+	lds_put_small(out, (pbase + (hi & 0xFFFu)) * 8u, minv, normal & (((hi >> 12) & 1u) == U32(1u)));
+	{
+		// mins rle mask (:765): bit r = min equals previous min
+		const uint64_t eqb = ballot(((hi >> 13) & 1u) == U32(1u));
+		const U32 half = sel(s < U32(2u), U32((uint32_t)eqb), U32((uint32_t)(eqb >> 32)));
+		const U32 m16 = (half >> ((s & 1u) << 4)) & 0xFFFFu;
+		lds_put_bits(out, (pbase + 8u) * 8u, m16, svalid & (type == U32(PLANE_NORMAL_RLE)) & (r == U32(0u)));
+	}
+	WV_MARK("emit_plane");
+	// the row's 16 bytes and their deltas against the previous byte in plane order, 0 before the plane (:399-401)
+	U128 bv = lds_ld128(lds, U32(slot_image(L, 0)) + s * SLOT_STRIDE + r * 16u);
+	U32 b[4], d[4];
+	b[0] = bv.x;
+	b[1] = bv.y;
+	b[2] = bv.z;
+	b[3] = bv.w;
+	const U32 prev = row_shr(b[3] >> 24, 1, 0);
+	d[0] = bytes_sub(b[0], (b[0] << 8) | prev);
+	for (int k = 1; k < 4; ++k)
+		d[k] = bytes_sub(b[k], (b[k] << 8) | (b[k - 1] >> 24));
+	const Pred is15 = hdr == U32(15u), is7 = hdr == U32(7u), is6 = hdr == U32(6u);
+	const U32 bits = hdr & 7u;
+	const Pred rawrow = israw | (normal & is15);
+	const Pred packed = normal & !is15 & !is7 & !is6 & (bits != U32(0u));
+	const Pred rle = normal & (is7 | is6);
+	const U32 rbase = sel(israw, pbase + r * 16u, pbase + (lo >> 16));
+	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each
+	const Pred usedelta = hdr >= U32(8u);
+	const U32 mins = bytes_splat(minv);
+	U32 pk[4];
+	for (int k = 0; k < 4; ++k)
+		pk[k] = pack4(bytes_sub(sel(usedelta, d[k], b[k]), mins), bits);
+	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
+	const Pred anyw = rawrow | packed;
+	const U32 own = lane * 4u; // where lanes without a row payload OR their zeros
+	U32 s0lo = sel(rawrow, b[0], sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
+	U32 s0hi = sel(rawrow, b[1], sel(packed, pk[1] >> ish4, U32(0u)));
+	U32 s1lo = sel(rawrow, b[2], sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
+	U32 s1hi = sel(rawrow, b[3], sel(packed, pk[3] >> ish4, U32(0u)));
+	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
+	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
+	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
+	if (any(rle)) {
+		U32 f16(0u), lp = rbase + 2u;
+		for (int k = 0; k < 4; ++k) {
+			const U32 pd = k ? (d[k - 1] >> 24) : U32(0u);
+			const U32 z = bytes_zero_mask(sel(is7, d[k], d[k] ^ ((d[k] << 8) | pd))); // byte == previous byte (:268-275) / delta == previous delta (:248-255)
+			const U32 f = zero_mask_to_bits(z);
+			f16 = f16 | (f << U32(4u * (uint32_t)k));
+			const U32 nlit = U32(4u) - popc(f);
+			lds_put_bits(out, lp * 8u, compact_unflagged(sel(is7, b[k], d[k]), f), rle & (nlit != U32(0u)));
+			lp = lp + nlit;
+		}
+		lds_put_bits(out, rbase * 8u, f16, rle);
+	}
+	WV_MARK("emit_end");
+	wave_sync();
+}
+
 // zero `bytes` (multiple of 16, 16-byte aligned) of LDS at `off`
 WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
 {
@@ -719,13 +849,14 @@ WV_FN U32 lz_hash(const LzVal& v, uint32_t B)
 // Try to encode the block held at L.in with the mini-LZ.  Returns the number of bytes produced
 // (after the 253 marker) or 0 when the reference would give up.  On success the stream has been
 // written to the zeroed output image at byte base+1 and the marker at base.
-// *scratch_used (optional) is set once the attempt gets past its first rejection test and starts using L.lz.
-WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base, bool* scratch_used = nullptr)
+// First rejection test of the mini-LZ, on its own: false when the attempt is hopeless.  Uses only L.in and the first
+// KiB of the image (not L.lz).
+WV_FN bool lz_precheck(Lds lds, const Layout& L, uint32_t T, uint32_t max_size)
 {
 	const U32 lane = lane_id();
 	const uint32_t B = lz_width(T);
-	const uint32_t count = 256 * T / B, nchunks = count / 64;
-	const uint32_t tab = L.out, chain = L.lz, cur = chain + count * 4; // the image is written last: its first KiB serves as the table
+	const uint32_t count = 256 * T / B;
+	const uint32_t tab = L.out;
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
 	WV_MARK("lz_try");
 
@@ -753,8 +884,20 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		wave_sync();
 		const uint32_t lower = (gq + 1) + nq * B - (nq - distinct) * (B - 1);
 		if (lower > max_size || (double)lower > (double)max_size * 0.4)
-			return 0;
+			return false;
 	}
+	return true;
+}
+// *scratch_used (optional) is set once the attempt gets past its first rejection test and starts using L.lz.
+WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base, bool* scratch_used = nullptr)
+{
+	const U32 lane = lane_id();
+	const uint32_t B = lz_width(T);
+	const uint32_t count = 256 * T / B, nchunks = count / 64;
+	const uint32_t tab = L.out, chain = L.lz, cur = chain + count * 4; // the image is written last: its first KiB serves as the table
+	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
+	if (!lz_precheck(lds, L, T, max_size))
+		return 0;
 	if (scratch_used)
 		*scratch_used = true;
 

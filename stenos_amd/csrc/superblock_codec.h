@@ -148,100 +148,6 @@ WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 	gst8(rs.base + (rs.pos - r), lane, lds_ld8(lds, U32(out - 16u) + sel(t, lane, U32(0u))), t);
 }
 
-// The same for a block of bytesoftype 2 or 4 whose non-constant planes have been analysed in slots slot_lo, slot_lo + 1, ...
-// (L.plinfo[slot] = type | size << 8).  raw: the block in HBM when L.in does not hold it yet (only the mini-LZ reads L.in),
-// null when it does.  *dirty: the slot images may have been overwritten by an LZ attempt (they share its scratch); set
-// here when this block's attempt does so.
-WV_FN BlockInfo finish_block(Lds lds, const Layout& L, uint32_t T, bool allow_lz, uint32_t base, const SameScan& sc, uint32_t slot_lo,
-			     const uint8_t* raw, bool* dirty)
-{
-	uint32_t tab[4] = { 0u, 0u, 0u, 0u }; // per plane: type | offset << 8 | slot << 24
-	SlotMap sm;
-	uint32_t full, need;
-	if (T <= 2) {
-		// two planes: scalars are the shorter way
-		const U32 pinfo = lds_ld32(lds, U32(L.plinfo) + (lane_id() & 3u) * 4u); // lane q: the entry of slot q
-		uint32_t slot = slot_lo, slots[2] = { 0u, 0u };
-		for (uint32_t k = 0; k < T; ++k) {
-			if ((sc.act >> k) & 1u) {
-				tab[k] = readlane(pinfo, slot);
-				slots[k] = slot;
-				++slot;
-			}
-			else
-				tab[k] = PLANE_SAME | (1u << 8);
-		}
-		WV_MARK("plane_offsets");
-		uint32_t nib = 0;
-		for (uint32_t k = 0; k < T; ++k)
-			nib |= (tab[k] & 0xFu) << (4 * k);
-		full = plane_offsets_small(T, true, 16, tab, &need);
-		for (uint32_t k = 0; k < T; ++k)
-			tab[k] |= slots[k] << 24;
-		sm.first = sc.first;
-		sm.nib = U32(nib);
-	}
-	else {
-		// The plane table is built on lanes (lane k of every quad: plane k) and only its results become scalars: scalar
-		// instructions cost an issue slot like vector ones, and tables indexed by run-time values would leave the registers.
-		const U32 lane = lane_id();
-		const U32 k = lane & 3u;
-		const Pred inblock = k < U32(T);
-		const Pred active = inblock & (((U32(sc.act) >> k) & 1u) == U32(1u));
-		const U32 slotv = U32(slot_lo) + popc(U32(sc.act) & ((U32(1u) << k) - 1u)); // slots follow the plane order
-		U32 pinfo = lds_ld32(lds, U32(L.plinfo) + sel(active, slotv, U32(0u)) * 4u);
-		pinfo = sel(active, pinfo, sel(inblock, U32(PLANE_SAME | (1u << 8)), U32(0u)));
-		const U32 type = pinfo & 0xFFu, size = pinfo >> 8;
-		WV_MARK("plane_offsets");
-		U32 incl = size + sel(k >= U32(1u), row_shr(size, 1, 0), U32(0u)); // prefix sums inside the quad
-		incl = incl + sel(k >= U32(2u), row_shr(incl, 2, 0), U32(0u));
-		const uint32_t hs = header_bytes(T);
-		const U32 off = U32(hs) + incl - size;
-		full = readlane(incl, 3);
-		// capacity the plane loop needs (block_compress.h:1241): see plane_offsets
-		const uint32_t m = readlane(quad_max(sel(inblock & (type != U32(PLANE_RAW)), off + size + 16u, U32(0u))), 0);
-		need = m > hs + full ? m : hs + full;
-		const U32 tabv = type | (off << 8) | (sel(active, slotv, U32(0u)) << 24);
-		for (uint32_t j = 0; j < 4; ++j)
-			tab[j] = readlane(tabv, j);
-		sm.first = sc.first;
-		sm.nib = quad_add(sel(inblock, type << (k << 2), U32(0u)));
-	}
-	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
-	BlockInfo r;
-	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
-	bool have_raw = raw == nullptr;
-	if (allow_lz && eligible) {
-		if (!have_raw) {
-			load_block(lds, L.in, raw, 256 * T);
-			wave_sync();
-			have_raw = true;
-		}
-		uint32_t n = lz_try(lds, L, T, full, base, dirty);
-		if (n) {
-			r.size = n + 1;
-			r.info |= 1u << 31;
-			return r;
-		}
-	}
-	if (*dirty) { // rare: the planes of this block go back into their slots
-		if (!have_raw) {
-			load_block(lds, L.in, raw, 256 * T);
-			wave_sync();
-		}
-		write_slots(lds, L, load_plane_regs(lds, L.in, T, 0), T, sc.act, slot_lo);
-		wave_sync();
-	}
-	WV_MARK("image_reset");
-	image_reset(lds, L, base, header_bytes(T) + full);
-	PlaneRegs none;
-	none.valid = false;
-	none.g = 0;
-	emit_planes(lds, L, T, base, 16, none, tab, &sm);
-	r.size = header_bytes(T) + full;
-	return r;
-}
-
 // `nblocks` full blocks at src -> their encodings, back to back, at stage (16-byte aligned, room for
 // nblocks * max_block_bytes(T) + 16).  Ample capacity is assumed (the mini-LZ is always tried), which is
 // what the reference does for every superblock but the ones at the very end of a tight buffer.
@@ -294,19 +200,75 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 			wave_sync();
 			if (nslots)
 				analyse_slots(lds, L, nslots);
-			// the blocks of the batch, one after the other
-			const uint32_t nblk = pair ? 2u : 1u;
-			bool dirty = false;
-			for (uint32_t k = 0; k < nblk; ++k) {
-				SameScan sc;
-				sc.act = k ? sb.act : sa.act;
-				sc.nact = k ? sb.nact : sa.nact;
-				sc.first = k ? sb.first : sa.first;
-				const BlockInfo r = finish_block(lds, L, T, true, rs.pos & 15u, sc, k ? sa.nact : 0u, k ? b : nullptr, &dirty);
-				WV_MARK("stream_append");
-				stream_append(rs, lds, L.out, r.size);
-				WV_MARK("block_end");
+			const uint32_t nblk = pair ? 2u : 1u, hs = header_bytes(T);
+			const uint32_t act1 = pair ? sb.act : 0u;
+			uint32_t full0, full1;
+			{
+				const BatchPlan P = plan_batch(lds, L, T, sa.act, act1, nblk);
+				full0 = P.full[0];
+				full1 = P.full[1];
 			}
+			const uint32_t size0 = hs + full0, size1 = pair ? hs + full1 : 0u;
+			uint32_t pending = pair ? 3u : 1u; // blocks whose planes still have to be written
+			// Blocks that try the mini-LZ (block_compress.h:1210-1221).  Its table is the image, so the second block's
+			// attempt has to wait until the first block is out: it is only made when it passes the first rejection test
+			// (most do not), otherwise both blocks are written in one pass.  Only the mini-LZ reads L.in.
+			uint32_t lzq = 0;
+			if (T % 4 == 0) {
+				lzq = full0 * 3 > bs ? 1u : 0u;
+				if (pair && full1 * 3 > bs) {
+					load_block(lds, L.in, b, bs);
+					wave_sync();
+					if (lz_precheck(lds, L, T, full1))
+						lzq |= 2u;
+					if (lzq & 1u) { // the first block's attempt needs its bytes back
+						load_block(lds, L.in, a, bs);
+						wave_sync();
+					}
+				}
+			}
+			bool dirty = false; // an attempt has overwritten the slot images (they share its scratch)
+			for (;;) {
+				const uint32_t blk = (lzq & 1u) ? 0u : 1u;
+				if (lzq && !(blk == 1u && (pending & 1u))) {
+					lzq &= ~(1u << blk);
+					if (blk == 1u) {
+						load_block(lds, L.in, b, bs);
+						wave_sync();
+					}
+					const uint32_t n = lz_try(lds, L, T, blk ? full1 : full0, rs.pos & 15u, &dirty);
+					if (n) {
+						stream_append(rs, lds, L.out, n + 1);
+						pending &= ~(1u << blk);
+					}
+					continue;
+				}
+				if (!pending)
+					break;
+				// write planes: both blocks in one pass, back to back in the image, when nothing stands in between
+				uint32_t mask = (pending & 1u) ? 1u : 2u;
+				if (pending == 3u && !lzq && (rs.pos & 15u) + size0 + size1 + 32u <= out_capacity(T))
+					mask = 3u;
+				if (dirty) { // rare: the planes go back into their slots
+					for (uint32_t q = 0; q < nblk; ++q) {
+						load_block(lds, L.in, q ? b : a, bs);
+						wave_sync();
+						write_slots(lds, L, load_plane_regs(lds, L.in, T, 0), T, q ? sb.act : sa.act, q ? sa.nact : 0u);
+						wave_sync();
+					}
+					dirty = false;
+				}
+				const uint32_t base = rs.pos & 15u;
+				const uint32_t bytes = ((mask & 1u) ? size0 : 0u) + ((mask & 2u) ? size1 : 0u);
+				const BatchPlan P = plan_batch(lds, L, T, sa.act, act1, nblk);
+				WV_MARK("image_reset");
+				image_reset(lds, L, base, bytes);
+				emit_batch(lds, L, T, P, sa.first, sb.first, mask, base, (mask & 1u) ? base + size0 : base, sa.nact, nslots);
+				WV_MARK("stream_append");
+				stream_append(rs, lds, L.out, bytes);
+				pending &= ~mask;
+			}
+			WV_MARK("block_end");
 			i += pair ? 2u : 1u;
 		}
 		stream_flush(rs, lds, L.out);

@@ -180,6 +180,22 @@ WV_FN U32 perm_bytes(const U32& hi, const U32& lo, uint32_t selw)
 	}
 	return r;
 }
+// the same with a selector per lane
+WV_FN U32 perm_bytes_v(const U32& hi, const U32& lo, const U32& selw)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint64_t both = ((uint64_t)hi.l[i] << 32) | lo.l[i];
+		uint32_t v = 0;
+		for (int k = 0; k < 4; ++k) {
+			uint32_t sb = (selw.l[i] >> (8 * k)) & 0xFF;
+			uint32_t byte = sb < 8 ? (uint32_t)((both >> (8 * sb)) & 0xFF) : 0u;
+			v |= byte << (8 * k);
+		}
+		r.l[i] = v;
+	}
+	return r;
+}
 WV_FN uint64_t ballot(const Pred& p)
 {
 	uint64_t m = 0;
@@ -289,6 +305,16 @@ WV_FN U32 lds_cas32(Lds m, const U32& a, const U32& expect, const U32& v, const 
 			if (t == expect.l[i]) memcpy(m + (a.l[i] & ~3u), &v.l[i], 4);
 		}
 	return r;
+}
+// every lane ORs v into the dword at a (a multiple of 4)
+WV_FN void lds_or32_all(Lds m, const U32& a, const U32& v)
+{
+	for (int i = 0; i < WAVE; ++i) {
+		uint32_t t;
+		memcpy(&t, m + a.l[i], 4);
+		t |= v.l[i];
+		memcpy(m + a.l[i], &t, 4);
+	}
 }
 WV_FN void lds_or32(Lds m, const U32& a, const U32& v, const Pred& p)
 {
@@ -436,6 +462,7 @@ WV_FN U32 pk_max_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_el
 WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
 WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
+WV_FN U32 perm_bytes_v(U32 hi, U32 lo, U32 selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __ballot(p); }
 WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }
 // 1 when the lane mask is not empty, else 0 -- as an integer in a scalar register (a C++ bool would be kept as a
@@ -557,6 +584,7 @@ WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
 }
 // OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
 // at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)
+WV_FN void lds_or32_all(Lds m, U32 a, U32 v) { __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_FN void lds_or32(Lds m, U32 a, U32 v, Pred p)
 {
 	__hip_atomic_fetch_or((uint32_t*)(m + (p ? (a & ~3u) : lane_id() * 4u)), p ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -654,6 +682,18 @@ WV_FN void lds_put_bits(Lds m, const U32& bitpos, const U32& value, const Pred& 
 	lds_or32(m, addr, value << sh, p);
 	U32 hi = sel(sh == U32(0u), U32(0u), value >> (U32(32u) - sh));
 	lds_or32(m, addr + 4u, hi, p); // hi == 0 ORs nothing; the image has 4 bytes of slack
+}
+
+// OR the 8 bytes lo, hi (little endian) into the zeroed LDS image at byte position pos, by every lane; lanes with nothing
+// to write pass zeros and a position of their own.  Three aligned dwords, shifted with one byte permute each.
+WV_FN void lds_put_bytes8(Lds m, const U32& pos, const U32& lo, const U32& hi)
+{
+	const U32 a = pos & ~3u;
+	const U32 selw = U32(0x07060504u) - (pos & 3u) * 0x01010101u; // bytes 4-k .. 7-k of the pair {upper, lower}
+	const U32 zero(0u);
+	lds_or32_all(m, a, perm_bytes_v(lo, zero, selw));
+	lds_or32_all(m, a + 4u, perm_bytes_v(hi, lo, selw));
+	lds_or32_all(m, a + 8u, perm_bytes_v(zero, hi, selw));
 }
 
 // same for a value that cannot straddle a dword: a nibble at a nibble-aligned position, a byte at a byte-aligned one
