@@ -898,16 +898,35 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
 	if (!lz_precheck(lds, L, T, max_size))
 		return 0;
+	{
+		// Second rejection test, for data whose values hardly repeat (noise, floats): a value can only match when an
+		// equal value precedes it, and equal values have equal hashes.  A 13-bit hash and one bit per hash value (1 KiB,
+		// the image area again) give an upper bound `maybe` of the values with an equal predecessor, so the whole stream
+		// takes at least ngroups + count*B - maybe*(B-1) bytes; above max_size the reference fails (lz_compress.h:221-223)
+		// after doing all the work.  Leaves L.lz alone.
+		U128 z;
+		z.x = z.y = z.z = z.w = U32(0u);
+		lds_st128(lds, U32(tab) + lane * 16u, z, pred_all(true));
+		wave_sync();
+		uint32_t maybe = 0;
+		for (uint32_t c = 0; c < nchunks; ++c) {
+			LzVal v = lz_value(lds, L.in, B, U32(c * 64u) + lane);
+			U32 h = ((v.lo ^ (v.hi * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 19;
+			U32 bit = U32(1u) << (h & 31u);
+			U32 old = lds_or_rtn32(lds, U32(tab) + (h >> 5) * 4u, bit);
+			maybe += (uint32_t)__builtin_popcountll(ballot((old & bit) != U32(0u)));
+		}
+		wave_sync();
+		if (count / 8 + count * B - maybe * (B - 1) > max_size)
+			return 0;
+	}
 	if (scratch_used)
 		*scratch_used = true;
 
 	{
-		// Second rejection test, for data whose values hardly repeat (floats, noise): a value can only match
-		// when an equal value precedes it, so with `dups` = values that have an equal predecessor the whole
-		// stream takes at least ngroups + count*B - dups*(B-1) bytes; above max_size the reference fails
-		// (lz_compress.h:221-223) after doing all the work.  Distinct values are counted with an
-		// open-addressing table of positions (2*count slots in the chain/candidate area, linear probing,
-		// LDS compare-and-swap).
+		// Third rejection test: the same bound with the exact number `dups` of values that have an equal predecessor.
+		// Distinct values are counted with an open-addressing table of positions (2*count slots in the chain/candidate
+		// area, linear probing, LDS compare-and-swap).
 		const uint32_t slots = 2 * count;
 		for (uint32_t o = 0; o < slots * 4; o += 1024) {
 			U128 none;
@@ -1226,6 +1245,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
 	const uint32_t nh = (lines + 1) >> 1;
+	WV_MARK("dec_plane_rows");
 	// ---- row view: every group of 16 lanes computes the same 16 rows ----
 	const U32 r = lane & 15u;
 	const Pred act = r < U32(lines);
@@ -1280,6 +1300,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		return DEC_ERROR;
 	U32 poff = U32(base) + pre + extra;
 
+	WV_MARK("dec_plane_elems");
 	// ---- element view: lane l owns elements 4l..4l+3, its row is l>>2 ----
 	const U32 row = lane >> 2, q = lane & 3u;
 	U32 info = shfl(hdr | (minv << 8) | (poff << 16), row);
@@ -1321,7 +1342,9 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	}
 	else
 		outw = Bw;
+	WV_MARK("dec_plane_store");
 	store_plane_word(lds, L.img, T, j, outw, eact);
+	WV_MARK("dec_plane_end");
 	return psize;
 }
 
@@ -1429,6 +1452,7 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	uint32_t p = cur + hs;
 	const uint32_t end = cur + avail;
 	for (uint32_t j = 0; j < T; ++j) {
+		WV_MARK("dec_plane_type");
 		uint32_t type = (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
 		if (type == PLANE_SAME) { // (:1567-1583)
 			if (p >= end)

@@ -432,12 +432,15 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 	};
 
 	for (uint32_t b = 0; b < nblocks; ++b) {
+		WV_MARK("dec_block_begin");
 		uint32_t left = csize - consumed;
 		uint32_t need = left < max_block_bytes(T) ? left : max_block_bytes(T);
 		ensure(need);
+		WV_MARK("dec_block");
 		uint32_t n = decode_block(lds, L, T, consumed + mis - wstart, need, 16, true);
 		if (n == DEC_ERROR)
 			return DEC_ERROR;
+		WV_MARK("dec_block_store");
 		store_block(dst + (size_t)b * bs, lds, L.img, bs);
 		wave_sync();
 		consumed += n;

@@ -306,6 +306,19 @@ WV_FN U32 lds_cas32(Lds m, const U32& a, const U32& expect, const U32& v, const 
 		}
 	return r;
 }
+// atomic OR returning the previous value (lane order on the host; any order is a valid device order)
+WV_FN U32 lds_or_rtn32(Lds m, const U32& a, const U32& v)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint32_t t;
+		memcpy(&t, m + a.l[i], 4);
+		r.l[i] = t;
+		t |= v.l[i];
+		memcpy(m + a.l[i], &t, 4);
+	}
+	return r;
+}
 // every lane ORs v into the dword at a (a multiple of 4)
 WV_FN void lds_or32_all(Lds m, const U32& a, const U32& v)
 {
@@ -584,6 +597,7 @@ WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
 }
 // OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
 // at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)
+WV_FN U32 lds_or_rtn32(Lds m, U32 a, U32 v) { return __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_FN void lds_or32_all(Lds m, U32 a, U32 v) { __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_FN void lds_or32(Lds m, U32 a, U32 v, Pred p)
 {
