@@ -849,45 +849,67 @@ WV_FN U32 lz_hash(const LzVal& v, uint32_t B)
 // Try to encode the block held at L.in with the mini-LZ.  Returns the number of bytes produced
 // (after the 253 marker) or 0 when the reference would give up.  On success the stream has been
 // written to the zeroed output image at byte base+1 and the marker at base.
-// First rejection test of the mini-LZ, on its own: false when the attempt is hopeless.  Uses only L.in and the first
-// KiB of the image (not L.lz).
-WV_FN bool lz_precheck(Lds lds, const Layout& L, uint32_t T, uint32_t max_size)
+// First rejection test of the mini-LZ (most attempts end here).  Every value costs B bytes unless it matches (>= 1 byte)
+// and only values with an earlier same-hash value can match; each group adds its flag byte (lz_compress.h:203-219).
+// Counting the distinct hash keys among the first nq values gives a lower bound of the bytes produced when the
+// reference runs its early-stop test; if even that bound fails the test (:221-229) the attempt is over without
+// building the chains.  nq: values covered up to and including the first group whose start index exceeds count/4.
+WV_HD uint32_t lz_precheck_values(uint32_t T)
+{
+	const uint32_t count = 256 * T / lz_width(T);
+	return 8 * ((count / 4) / 8 + 2);
+}
+WV_HD bool lz_precheck_passes(uint32_t T, uint32_t distinct, uint32_t max_size)
+{
+	const uint32_t B = lz_width(T), nq = lz_precheck_values(T);
+	const uint32_t lower = nq / 8 + nq * B - (nq - distinct) * (B - 1);
+	return !(lower > max_size || (double)lower > (double)max_size * 0.4);
+}
+// distinct hash keys among the first nq values of the block at L.in; uses the first KiB of the image (not L.lz)
+WV_FN uint32_t lz_distinct_keys(Lds lds, const Layout& L, uint32_t T)
 {
 	const U32 lane = lane_id();
 	const uint32_t B = lz_width(T);
-	const uint32_t count = 256 * T / B;
 	const uint32_t tab = L.out;
-	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
+	const uint32_t nq = lz_precheck_values(T);
 	WV_MARK("lz_try");
-
-	const uint32_t gq = quarter / 8 + 1; // first group whose start index exceeds count/4: the early-stop test runs after it
-	const uint32_t nq = 8 * (gq + 1);    // values covered up to and including that group
-	const uint32_t cq = (nq - 1) / 64;   // chunk that holds its last value
-	{
-		// Cheap rejection of hopeless attempts (most of them).  Every value costs B bytes unless it matches
-		// (>= 1 byte) and only values with an earlier same-hash value can match; each group adds its flag
-		// byte (lz_compress.h:203-219).  Counting the distinct hash keys among the first nq values gives a
-		// lower bound of the bytes produced when the reference runs its early-stop test; if even that bound
-		// fails the test (:221-229) the attempt is over without building the chains.
-		U128 z;
-		z.x = z.y = z.z = z.w = U32(0u);
-		lds_st128(lds, U32(tab) + lane * 16u, z, pred_all(true)); // 256 counters
-		wave_sync();
-		uint32_t distinct = 0;
-		for (uint32_t c = 0; c <= cq; ++c) {
-			const U32 pos = U32(c * 64u) + lane;
-			Pred in = pos < U32(nq);
-			U32 key = lz_hash(lz_value(lds, L.in, B, sel(in, pos, U32(0u))), B);
-			U32 old = lds_add_rtn32(lds, U32(tab) + key * 4u, U32(1u), in);
-			distinct += (uint32_t)__builtin_popcountll(ballot(in & (old == U32(0u))));
-		}
-		wave_sync();
-		const uint32_t lower = (gq + 1) + nq * B - (nq - distinct) * (B - 1);
-		if (lower > max_size || (double)lower > (double)max_size * 0.4)
-			return false;
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	lds_st128(lds, U32(tab) + lane * 16u, z, pred_all(true)); // 256 counters
+	wave_sync();
+	uint32_t distinct = 0;
+	for (uint32_t c = 0; c <= (nq - 1) / 64; ++c) {
+		const U32 pos = U32(c * 64u) + lane;
+		Pred in = pos < U32(nq);
+		U32 key = lz_hash(lz_value(lds, L.in, B, sel(in, pos, U32(0u))), B);
+		U32 old = lds_add_rtn32(lds, U32(tab) + key * 4u, U32(1u), in);
+		distinct += (uint32_t)__builtin_popcountll(ballot(in & (old == U32(0u))));
 	}
-	return true;
+	wave_sync();
+	return distinct;
 }
+// the same for a block of bytesoftype 4 that is still in registers (the lane's four elements): the first nq = 80
+// values are those of lanes 0..19
+WV_FN uint32_t lz_distinct_keys_regs(Lds lds, const Layout& L, const U128& e)
+{
+	const U32 lane = lane_id();
+	const uint32_t tab = L.out;
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	lds_st128(lds, U32(tab) + lane * 16u, z, pred_all(true));
+	wave_sync();
+	const Pred in = lane < U32(lz_precheck_values(4) / 4);
+	uint32_t distinct = 0;
+	const U32 v[4] = { e.x, e.y, e.z, e.w };
+	for (int k = 0; k < 4; ++k) {
+		U32 key = (v[k] * 2654435761u) & 255u; // hash_val (lz_compress.h:47-56)
+		U32 old = lds_add_rtn32(lds, U32(tab) + key * 4u, U32(1u), in);
+		distinct += (uint32_t)__builtin_popcountll(ballot(in & (old == U32(0u))));
+	}
+	wave_sync();
+	return distinct;
+}
+WV_FN bool lz_precheck(Lds lds, const Layout& L, uint32_t T, uint32_t max_size) { return lz_precheck_passes(T, lz_distinct_keys(lds, L, T), max_size); }
 // *scratch_used (optional) is set once the attempt gets past its first rejection test and starts using L.lz.
 WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base, bool* scratch_used = nullptr)
 {

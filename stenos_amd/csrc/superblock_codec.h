@@ -171,16 +171,20 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 			const bool has_b = fast && i + 1 < nblocks;
 			PlaneRegs ra;
 			RawBlock eb;
+			uint32_t keys0 = 0, keys1 = 0; // distinct hash keys at the head of each block (first rejection test of the mini-LZ)
 			if (fast) {
 				const RawBlock ea = load_raw_block(a, T);
 				if (has_b)
 					eb = load_raw_block(b, T);
-				store_raw_block(lds, L.in, ea, T);
+				if (T == 4)
+					keys0 = lz_distinct_keys_regs(lds, L, ea.e);
 				ra = plane_regs_of(ea, T);
 			}
 			else {
 				load_block(lds, L.in, a, bs);
 				wave_sync();
+				if (T == 4)
+					keys0 = lz_distinct_keys(lds, L, T);
 				ra = load_plane_regs(lds, L.in, T, 0);
 			}
 			WV_MARK("block_begin");
@@ -194,6 +198,8 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 				if (sa.nact + sb.nact <= 4) {
 					write_slots(lds, L, rb, T, sb.act, sa.nact);
 					pair = true;
+					if (T == 4)
+						keys1 = lz_distinct_keys_regs(lds, L, eb.e);
 				}
 			}
 			const uint32_t nslots = sa.nact + (pair ? sb.nact : 0u);
@@ -210,32 +216,23 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 			}
 			const uint32_t size0 = hs + full0, size1 = pair ? hs + full1 : 0u;
 			uint32_t pending = pair ? 3u : 1u; // blocks whose planes still have to be written
-			// Blocks that try the mini-LZ (block_compress.h:1210-1221).  Its table is the image, so the second block's
-			// attempt has to wait until the first block is out: it is only made when it passes the first rejection test
-			// (most do not), otherwise both blocks are written in one pass.  Only the mini-LZ reads L.in.
+			// Blocks that try the mini-LZ (block_compress.h:1210-1221): those that pass its first rejection test (most do
+			// not; the key counts were taken while the blocks were in registers).  Its table is the image, so the second
+			// block's attempt has to wait until the first block is out; otherwise both blocks are written in one pass.
 			uint32_t lzq = 0;
-			if (T % 4 == 0) {
-				lzq = full0 * 3 > bs ? 1u : 0u;
-				if (pair && full1 * 3 > bs) {
-					load_block(lds, L.in, b, bs);
-					wave_sync();
-					if (lz_precheck(lds, L, T, full1))
-						lzq |= 2u;
-					if (lzq & 1u) { // the first block's attempt needs its bytes back
-						load_block(lds, L.in, a, bs);
-						wave_sync();
-					}
-				}
+			if (T == 4) {
+				if (full0 * 3 > bs && lz_precheck_passes(T, keys0, full0))
+					lzq |= 1u;
+				if (pair && full1 * 3 > bs && lz_precheck_passes(T, keys1, full1))
+					lzq |= 2u;
 			}
 			bool dirty = false; // an attempt has overwritten the slot images (they share its scratch)
 			for (;;) {
 				const uint32_t blk = (lzq & 1u) ? 0u : 1u;
 				if (lzq && !(blk == 1u && (pending & 1u))) {
 					lzq &= ~(1u << blk);
-					if (blk == 1u) {
-						load_block(lds, L.in, b, bs);
-						wave_sync();
-					}
+					load_block(lds, L.in, blk ? b : a, bs); // only the mini-LZ reads L.in
+					wave_sync();
 					const uint32_t n = lz_try(lds, L, T, blk ? full1 : full0, rs.pos & 15u, &dirty);
 					if (n) {
 						stream_append(rs, lds, L.out, n + 1);
