@@ -446,6 +446,32 @@ WV_FN SameScan scan_same(const PlaneRegs& regs, uint32_t T)
 	}
 	return s;
 }
+// The same from the elements themselves (bytesoftype 2 or 4): byte k of the OR over all elements of (element ^ first
+// element) is non-zero exactly when plane k is not constant.  Fewer scalar instructions than four separate tests.
+WV_FN SameScan scan_same_raw(const RawBlock& b, uint32_t T)
+{
+	SameScan s;
+	U32 x;
+	if (T == 2) {
+		const uint32_t e0 = readlane(b.e.x, 0) & 0xFFFFu;
+		const U32 e(e0 * 0x00010001u);
+		x = (b.e.x ^ e) | (b.e.y ^ e);
+		x = (x | (x >> 16)) & 0xFFFFu;
+		s.first = e0;
+	}
+	else {
+		const uint32_t e0 = readlane(b.e.x, 0);
+		const U32 e(e0);
+		x = ((b.e.x ^ e) | (b.e.y ^ e)) | ((b.e.z ^ e) | (b.e.w ^ e));
+		s.first = e0;
+	}
+	const uint32_t any = wave_or(x);
+	// lanes 0..3 look at one byte each
+	const U32 k = lane_id() & 3u;
+	s.act = (uint32_t)ballot(((U32(any) >> (k << 3)) & 0xFFu) != U32(0u)) & 0xFu;
+	s.nact = (uint32_t)__builtin_popcount(s.act);
+	return s;
+}
 WV_HD uint32_t slot_image(const Layout& L, uint32_t s) { return L.aux + 64 * 8 + s * SLOT_STRIDE; }
 // the non-constant planes of a block -> slots slot, slot + 1, ...
 WV_FN void write_slots(Lds lds, const Layout& L, const PlaneRegs& regs, uint32_t T, uint32_t act, uint32_t slot)

@@ -171,6 +171,7 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 			const bool has_b = fast && i + 1 < nblocks;
 			PlaneRegs ra;
 			RawBlock eb;
+			SameScan sa;
 			uint32_t keys0 = 0, keys1 = 0; // distinct hash keys at the head of each block (first rejection test of the mini-LZ)
 			if (fast) {
 				const RawBlock ea = load_raw_block(a, T);
@@ -178,7 +179,9 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 					eb = load_raw_block(b, T);
 				if (T == 4)
 					keys0 = lz_distinct_keys_regs(lds, L, ea.e);
+				WV_MARK("block_begin");
 				ra = plane_regs_of(ea, T);
+				sa = T == 4 ? scan_same_raw(ea, T) : scan_same(ra, T); // two planes: one test each is the shorter way
 			}
 			else {
 				load_block(lds, L.in, a, bs);
@@ -186,16 +189,22 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 				if (T == 4)
 					keys0 = lz_distinct_keys(lds, L, T);
 				ra = load_plane_regs(lds, L.in, T, 0);
+				sa = scan_same(ra, T);
 			}
-			WV_MARK("block_begin");
-			const SameScan sa = scan_same(ra, T);
 			write_slots(lds, L, ra, T, sa.act, 0);
 			SameScan sb = sa;
 			bool pair = false;
 			if (has_b && sa.nact <= 2) {
-				const PlaneRegs rb = plane_regs_of(eb, T);
-				sb = scan_same(rb, T);
+				PlaneRegs rb;
+				if (T == 4)
+					sb = scan_same_raw(eb, T);
+				else {
+					rb = plane_regs_of(eb, T);
+					sb = scan_same(rb, T);
+				}
 				if (sa.nact + sb.nact <= 4) {
+					if (T == 4)
+						rb = plane_regs_of(eb, T);
 					write_slots(lds, L, rb, T, sb.act, sa.nact);
 					pair = true;
 					if (T == 4)

@@ -762,6 +762,13 @@ WV_FN uint32_t wave_max(U32 x)
 	x = umax(x, shfl_xor(x, 32));
 	return readlane(x, 0);
 }
+// OR over the 64 lanes (uniform result)
+WV_FN uint32_t wave_or(const U32& x)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < WAVE; ++i) r |= x.l[i];
+	return r;
+}
 // inclusive prefix sum over the 64 lanes
 WV_FN U32 wave_incl_scan(U32 s)
 {
@@ -784,6 +791,15 @@ WV_FN uint32_t wave_max(U32 x)
 	a = a > b ? a : b;
 	c = c > d ? c : d;
 	return a > c ? a : c;
+}
+// OR over the 64 lanes: inside the rows with row_ror, then the four row results through scalar registers
+WV_FN uint32_t wave_or(U32 x)
+{
+	x |= row_ror(x, 8);
+	x |= row_ror(x, 4);
+	x |= row_ror(x, 2);
+	x |= row_ror(x, 1);
+	return readlane(x, 0) | readlane(x, 16) | readlane(x, 32) | readlane(x, 48);
 }
 // row_shr 1,2,4,8 with zero fill, then row_bcast:15 (0x142, rows 1 and 3) and row_bcast:31 (0x143, rows 2 and 3)
 WV_FN U32 wave_incl_scan(U32 s)
