@@ -1,0 +1,11 @@
+#!/bin/bash
+# GPU box: everything profiles/ needs for one checkpoint: bench line, kernel-trace statistics of the same command,
+# and the PMC passes (HBM traffic, instruction mix).  usage: bash tools/profile_round.sh <tag>
+R=$GRAFT_REPO_ROOT
+TAG=${1:-r01_vX}
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.log 2>&1 || exit 1
+rm -rf $R/gpurun_out/kt
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt -- python3 $R/bench.py --no-cpu-baseline --no-full-entropy > $R/gpurun_out/kt.log 2>&1 || exit 1
+find $R/gpurun_out/kt -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_kernel_stats_raw.csv \;
+bash $R/tools/pmc_run.sh 8
