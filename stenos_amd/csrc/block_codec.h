@@ -1480,7 +1480,9 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	const uint32_t hs = header_bytes(T);
 	if (avail <= hs) // src += header_len; src >= end  (block_compress.h:1819-1821)
 		return DEC_ERROR;
-	uint32_t first = win_u8(win, cur);
+	// the first four bytes of the encoding in one uniform read: the marker byte / all plane type nibbles up to bytesoftype 8
+	const uint32_t head = readlane(lds_ld32_unaligned(win, U32(cur)), 0);
+	uint32_t first = head & 0xFFu;
 	if (full && first == BLOCK_COPY) { // (:1823-1828)
 		if (avail < 1 + 256 * T)
 			return DEC_ERROR;
@@ -1501,7 +1503,7 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	const uint32_t end = cur + avail;
 	for (uint32_t j = 0; j < T; ++j) {
 		WV_MARK("dec_plane_type");
-		uint32_t type = (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
+		uint32_t type = j < 8 ? (head >> (4 * j)) & 15 : (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
 		if (type == PLANE_SAME) { // (:1567-1583)
 			if (p >= end)
 				return DEC_ERROR;

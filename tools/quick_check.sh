@@ -7,3 +7,7 @@ for cfg in "8 9 rand12 4" "4 9 walk 2" "4 9 sine 8"; do
   [ -f build/libstenos_base.so ] && { STENOS_LIB_PATH=$PWD/build/libstenos_base.so timeout -k 10 120 python tools/time_encode.py $cfg 2>/dev/null | grep kernel_ms || exit 1; }
   timeout -k 10 120 python tools/time_encode.py $cfg 2>/dev/null | grep kernel_ms || exit 1
 done
+for cfg in "8 9 rand12 4" "4 9 walk 2"; do
+  [ -f build/libstenos_base.so ] && { STENOS_LIB_PATH=$PWD/build/libstenos_base.so timeout -k 10 120 python tools/time_decode.py $cfg 2>/dev/null | grep kernel_ms || exit 1; }
+  timeout -k 10 120 python tools/time_decode.py $cfg 2>/dev/null | grep kernel_ms || exit 1
+done
