@@ -51,7 +51,8 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     same, sorted (lexicographically sorted random elements, signed bytes as std::array<char,N>),
     walk (x += u%17 - 8), dict16 (16-entry dictionary), runs (runs of 7), burst, ramp,
     sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal),
-    mixed (per block and plane: constant / narrow / random / walk / runs).
+    mixed (per block and plane: constant / narrow / random / walk / runs), lzmix (per block: noise / dictionary /
+    half dictionary / constant, 12-bit values).
     """
     if n == 0:
         return np.zeros(0, dtype=np.uint8)
@@ -103,6 +104,17 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
         runs = np.repeat(r[:, ::16, :], 16, axis=1)
         a = np.where(style <= 1, const, np.where(style == 2, narrow, np.where(style == 3, r, np.where(style == 4, walk, runs))))
         return np.ascontiguousarray(a.astype(np.uint8).reshape(nb * 256, T)[:n]).reshape(-1)
+    if kind == "lzmix":
+        # per 256-element block one of: 12-bit noise (no LZ), a 16-entry dictionary of 12-bit values (mini-LZ succeeds),
+        # a dictionary in the first half and noise behind it (an attempt that starts and fails), a constant block
+        nb = (n + 255) // 256
+        style = (splitmix64(seed + 11, nb) % np.uint64(4)).astype(np.int64)[:, None]
+        r = (splitmix64(seed + 5, nb * 256) & np.uint64(0xFFF)).astype(np.int64).reshape(nb, 256)
+        d = (splitmix64(seed + 6, nb * 16) & np.uint64(0xFFF)).astype(np.int64).reshape(nb, 16)
+        pick = np.take_along_axis(d, (r & 15), axis=1)
+        half = np.where(np.arange(256)[None, :] < 128, pick, r)
+        a = np.where(style == 0, r, np.where(style == 1, pick, np.where(style == 2, half, d[:, :1])))
+        return _le_elements(a.reshape(-1)[:n], T)
     if kind == "sine":
         x = np.sin(np.arange(n, dtype=np.float64) * 0.001)
         if T == 8:

@@ -75,7 +75,7 @@ def test_matrix_against_oracle(lib, ctx, oracle, T):
     the oracle's frames."""
     per_sb = 131072 // (256 * T) * 256
     sizes = [0, 1, 15, 16, 17, 100, 255, 256, 257, 511, 1280, 4099, per_sb - 1, per_sb, per_sb + 1, 2 * per_sb + 300]
-    for kind in ("rand", "same", "sorted", "walk", "dict16", "runs", "burst", "ramp", "mixed"):
+    for kind in ("rand", "same", "sorted", "walk", "dict16", "runs", "burst", "ramp", "mixed", "lzmix"):
         for n in sizes:
             data = generate(kind, T, n, 77 + n)
             r1, ref = oracle_compress(oracle, data, T, 1)
@@ -100,7 +100,7 @@ def test_readme_example(lib, ctx):
 
 
 @pytest.mark.parametrize("T,kind,n", [(4, "rand12", 5_000_011), (2, "walk", 9_000_001), (8, "sine", 2_000_003), (4, "dict16", 3_000_017),
-                                      (4, "rand", 1_000_003), (4, "burst", 4_000_001), (4, "mixed", 3_000_001), (2, "mixed", 5_000_003),
+                                      (4, "rand", 1_000_003), (4, "burst", 4_000_001), (4, "mixed", 3_000_001), (2, "mixed", 5_000_003), (4, "lzmix", 3_000_001), (8, "lzmix", 1_000_001),
                                       (4, "sorted", 2_000_001)])
 def test_medium_sizes_against_oracle(lib, ctx, oracle, T, kind, n):
     data = generate(kind, T, n, 42)
