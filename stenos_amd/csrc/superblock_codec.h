@@ -217,12 +217,9 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 				analyse_slots(lds, L, nslots);
 			const uint32_t nblk = pair ? 2u : 1u, hs = header_bytes(T);
 			const uint32_t act1 = pair ? sb.act : 0u;
-			uint32_t full0, full1;
-			{
-				const BatchPlan P = plan_batch(lds, L, T, sa.act, act1, nblk);
-				full0 = P.full[0];
-				full1 = P.full[1];
-			}
+			BatchPlan P = plan_batch(lds, L, T, sa.act, act1, nblk);
+			const uint32_t full0 = P.full[0], full1 = P.full[1];
+			bool replan = false; // an LZ attempt ran in between: the plan is rebuilt rather than kept in registers across it
 			const uint32_t size0 = hs + full0, size1 = pair ? hs + full1 : 0u;
 			uint32_t pending = pair ? 3u : 1u; // blocks whose planes still have to be written
 			// Blocks that try the mini-LZ (block_compress.h:1210-1221): those that pass its first rejection test (most do
@@ -242,6 +239,7 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 					lzq &= ~(1u << blk);
 					load_block(lds, L.in, blk ? b : a, bs); // only the mini-LZ reads L.in
 					wave_sync();
+					replan = true;
 					const uint32_t n = lz_try(lds, L, T, blk ? full1 : full0, rs.pos & 15u, &dirty);
 					if (n) {
 						stream_append(rs, lds, L.out, n + 1);
@@ -266,7 +264,10 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 				}
 				const uint32_t base = rs.pos & 15u;
 				const uint32_t bytes = ((mask & 1u) ? size0 : 0u) + ((mask & 2u) ? size1 : 0u);
-				const BatchPlan P = plan_batch(lds, L, T, sa.act, act1, nblk);
+				if (replan || T == 4) { // int32: rebuilding it is cheaper than the registers it would hold meanwhile
+					P = plan_batch(lds, L, T, sa.act, act1, nblk);
+					replan = false;
+				}
 				WV_MARK("image_reset");
 				image_reset(lds, L, base, bytes);
 				emit_batch(lds, L, T, P, sa.first, sb.first, mask, base, (mask & 1u) ? base + size0 : base, sa.nact, nslots);
