@@ -135,3 +135,23 @@ def test_frame_pipeline_and_capacity_rules(oracle, emul, T, fused):
     assert (fused_superblocks > 0) == bool(fused)
     if T % 4 == 0:
         assert replayed > 0, "no case exercised the capacity replay"
+
+
+@pytest.mark.parametrize("T", [2, 4])
+def test_fused_path_with_misaligned_source(oracle, emul, T):
+    """Blocks that do not start on 16-byte boundaries take the byte-wise loads of the slot encoder (superblock_codec.h, encode_run)."""
+    from _libs import oracle_compress
+
+    emul.emul_set_fused(1)
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    per = 131072 // (256 * T) * 256
+    for kind in ("mixed", "lzmix", "walk", "sorted"):
+        data = generate(kind, T, 2 * per + 300, 5)
+        r1, f1 = oracle_compress(oracle, data, T, 1)
+        for off in (1, 4, 8, 15):
+            buf = np.zeros(data.nbytes + 64, dtype=np.uint8)
+            buf[off:off + data.nbytes] = data
+            out = np.zeros(r1 + 5000, dtype=np.uint8)
+            r2 = emul.emul_compress_frame(np_ptr(buf) + off, T, data.nbytes, np_ptr(out), out.nbytes, 1)
+            assert r2 == r1 and np.array_equal(out[:r2], f1), (kind, off)

@@ -49,6 +49,35 @@ def test_device_roundtrip_large(st, kind, T, n):
     assert torch.equal(dst2[:csize], dst[:csize])
 
 
+@pytest.mark.parametrize("T,kind", [(4, "mixed"), (2, "walk"), (4, "lzmix"), (8, "sine")])
+def test_device_pointers_of_any_alignment(st, oracle, T, kind):
+    """Source, destination and decoded buffers that start at odd device addresses: the encoder's register path needs
+    16-byte aligned blocks and must fall back, the stores must not touch a byte outside their ranges."""
+    import torch
+    from _libs import oracle_compress
+
+    n = 600_003
+    data = generate(kind, T, n, 9)
+    r, ref = oracle_compress(oracle, data, T, 1)
+    for so, do in ((1, 0), (4, 3), (8, 5), (13, 16)):
+        buf = torch.zeros(data.nbytes + 64, dtype=torch.uint8, device="cuda")
+        buf[so:so + data.nbytes] = torch.from_numpy(data).cuda()
+        src = buf[so:so + data.nbytes]
+        out = torch.full((st.bound(data.nbytes) + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        dst = out[do:do + st.bound(data.nbytes)]
+        csize = st.compress(src, T, dst)
+        assert csize == r, (so, do)
+        got = out.cpu().numpy()
+        assert np.array_equal(got[do:do + csize], ref), (so, do)
+        assert (got[:do] == 0xA5).all() and (got[do + st.bound(data.nbytes):] == 0xA5).all(), (so, do)
+        back_buf = torch.full((data.nbytes + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        back = back_buf[do:do + data.nbytes]
+        assert st.decompress(dst, T, csize, back, index_ptr=None) == data.nbytes
+        b = back_buf.cpu().numpy()
+        assert np.array_equal(b[do:do + data.nbytes], data), (so, do)
+        assert (b[:do] == 0x5A).all() and (b[do + data.nbytes:] == 0x5A).all(), (so, do)
+
+
 def test_device_frame_equals_host_abi_frame(st):
     import torch
 
