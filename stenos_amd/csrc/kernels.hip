@@ -548,7 +548,9 @@ hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t fi
 template <uint32_t TT>
 static hipError_t launch_decode_t(const DecodeArgs& a, hipStream_t stream)
 {
-	const size_t lds = stenos_k_decode_lds_bytes(a.T);
+	size_t lds = stenos_k_decode_lds_bytes(a.T);
+	if (getenv("STENOS_EXP_DEC_LDS")) // occupancy experiments: a larger allocation leaves fewer waves per SIMD
+		lds = (size_t)atoi(getenv("STENOS_EXP_DEC_LDS"));
 	hipError_t e = hipFuncSetAttribute((const void*)decode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
