@@ -746,6 +746,8 @@ WV_FN void emit_batch(Lds lds, const Layout& L, uint32_t T, const BatchPlan& P, 
 		lds_st32(lds, U32(L.plinfo + 16u) + sel(P.active, P.slot, U32(0u)) * 4u, P.type | ((bbase + P.off) << 8), mine & P.active);
 		wave_sync();
 	}
+	if (((mask & 1u) ? nslots0 : 0u) + ((mask & 2u) ? nslots - nslots0 : 0u) == 0) // only constant planes: nothing for the slot lanes
+		return;
 	WV_MARK("emit_rowlanes");
 	const U32 s = lane >> 4, r = lane & 15u;
 	const U32 sinfo = lds_ld32(lds, U32(L.plinfo + 16u) + s * 4u);

@@ -177,11 +177,11 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 				const RawBlock ea = load_raw_block(a, T);
 				if (has_b)
 					eb = load_raw_block(b, T);
-				if (T == 4)
-					keys0 = lz_distinct_keys_regs(lds, L, ea.e);
 				WV_MARK("block_begin");
 				ra = plane_regs_of(ea, T);
 				sa = T == 4 ? scan_same_raw(ea, T) : scan_same(ra, T); // two planes: one test each is the shorter way
+				if (T == 4 && sa.nact >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
+					keys0 = lz_distinct_keys_regs(lds, L, ea.e);
 			}
 			else {
 				load_block(lds, L.in, a, bs);
@@ -207,7 +207,7 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 						rb = plane_regs_of(eb, T);
 					write_slots(lds, L, rb, T, sb.act, sa.nact);
 					pair = true;
-					if (T == 4)
+					if (T == 4 && sb.nact >= 2)
 						keys1 = lz_distinct_keys_regs(lds, L, eb.e);
 				}
 			}
