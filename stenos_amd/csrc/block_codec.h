@@ -1503,33 +1503,43 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	}
 	uint32_t p = cur + hs;
 	const uint32_t end = cur + avail;
+	// An error does not leave the loop: it is remembered and the remaining planes are skipped.  (A return from inside
+	// the loop costs a dozen scalar instructions of exit bookkeeping per plane, on the critical path of every block.)
+	uint32_t bad = 0;
 	for (uint32_t j = 0; j < T; ++j) {
 		WV_MARK("dec_plane_type");
+		if (bad)
+			continue;
 		uint32_t type = j < 8 ? (head >> (4 * j)) & 15 : (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
 		if (type == PLANE_SAME) { // (:1567-1583)
 			if (p >= end)
-				return DEC_ERROR;
-			U32 v = bytes_splat(lds_ld8(win, U32(p)));
-			store_plane_word(lds, L.img, T, j, v, (lane >> 2) < U32(lines));
-			p += 1;
+				bad = 1;
+			else {
+				U32 v = bytes_splat(lds_ld8(win, U32(p)));
+				store_plane_word(lds, L.img, T, j, v, (lane >> 2) < U32(lines));
+				p += 1;
+			}
 		}
 		else if (type == PLANE_RAW && full) { // (:1553-1565)
 			if (end - p < 256)
-				return DEC_ERROR;
-			store_plane_word(lds, L.img, T, j, lds_ld32_unaligned(win, U32(p) + lane * 4u), pred_all(true));
-			p += 256;
+				bad = 1;
+			else {
+				store_plane_word(lds, L.img, T, j, lds_ld32_unaligned(win, U32(p) + lane * 4u), pred_all(true));
+				p += 256;
+			}
 		}
 		else if (type == PLANE_NORMAL || (type == PLANE_NORMAL_RLE && full)) {
 			uint32_t n = decode_plane(lds, L, T, j, type, p, end - p, lines);
 			if (n == DEC_ERROR)
-				return DEC_ERROR;
-			p += n;
+				bad = 1;
+			else
+				p += n;
 		}
 		else
-			return DEC_ERROR; // (:1854-1855, 1779-1780)
+			bad = 1; // (:1854-1855, 1779-1780)
 	}
 	wave_sync();
-	return p - cur;
+	return bad ? DEC_ERROR : p - cur;
 }
 
 } // namespace codec
