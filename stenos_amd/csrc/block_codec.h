@@ -1299,26 +1299,23 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	// ---- row view: every group of 16 lanes computes the same 16 rows ----
 	const U32 r = lane & 15u;
 	const Pred act = r < U32(lines);
+	// No size checks here: whatever the stream says, a plane reads at most 8 + 18 + 16*18 + 8 bytes from its start (the
+	// window's buffer is followed by that much readable LDS, superblock_codec.h make_dec_layout) and the caller compares
+	// the bytes consumed by the whole block with the bytes there are (block_compress.h:1702, 1724-1745, 2056, 2071-2084).
+	(void)avail;
 	uint32_t minslen;
 	U32 hdr, minv;
+	hdr = (lds_ld8(win, U32(cur) + (r >> 1)) >> ((r & 1u) << 2)) & 0xFu;
 	if (type == PLANE_NORMAL) {
-		if (avail < nh + lines) // block_compress.h:1702, 2056
-			return DEC_ERROR;
-		hdr = (lds_ld8(win, U32(cur) + (r >> 1)) >> ((r & 1u) << 2)) & 0xFu;
 		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));
 		U32 e = sel(emit, U32(1u), U32(0u));
 		U32 ex = row_excl_scan(e);
 		minslen = readlane(row_add(e), 0);
 		minv = lds_ld8(win, U32(cur + nh) + sel(emit, ex, U32(0u)));
 	}
-	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins (:1724-1745, 2071-2084)
-		if (avail < 10)
-			return DEC_ERROR;
-		hdr = (lds_ld8(win, U32(cur) + (r >> 1)) >> ((r & 1u) << 2)) & 0xFu;
+	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins
 		uint32_t mask = win_u16(win, cur + 8);
 		uint32_t nlit = 16 - (uint32_t)__builtin_popcount(mask);
-		if (avail < 10 + nlit)
-			return DEC_ERROR;
 		minslen = 2 + nlit;
 		// min[r] = literal of the last row r' <= r whose mask bit is 0, or 0 when there is none
 		U32 upto = (~U32(mask)) & ((U32(2u) << r) - 1u) & 0xFFFFu;
@@ -1337,8 +1334,6 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		uint32_t rr = (uint32_t)__builtin_ctz(todo);
 		todo &= todo - 1;
 		uint32_t addr = base + readlane(pre + extra, rr);
-		if (addr + 2 > cur + avail)
-			return DEC_ERROR;
 		uint32_t m = win_u16(win, addr);
 		uint32_t sz = 2 + 16 - (uint32_t)__builtin_popcount(m);
 		rmask = sel(r == U32(rr), U32(m), rmask);
@@ -1346,8 +1341,6 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		rle_total += sz;
 	}
 	uint32_t psize = nh + minslen + readlane(row_add(known), 0) + rle_total;
-	if (psize > avail)
-		return DEC_ERROR;
 	U32 poff = U32(base) + pre + extra;
 
 	WV_MARK("dec_plane_elems");
@@ -1503,43 +1496,30 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	}
 	uint32_t p = cur + hs;
 	const uint32_t end = cur + avail;
-	// An error does not leave the loop: it is remembered and the remaining planes are skipped.  (A return from inside
-	// the loop costs a dozen scalar instructions of exit bookkeeping per plane, on the critical path of every block.)
+	// No bounds check per plane (the bytes a block can read past its start are bounded and readable, see decode_plane):
+	// an invalid plane type is remembered, and the bytes consumed are compared with the bytes there are once, at the end
+	// -- a truncated stream cannot satisfy that (block_compress.h:1560, 1575, 1591-1598, 1642).  Returns from inside the
+	// loop would cost a dozen scalar instructions of exit bookkeeping per plane on every block's critical path.
 	uint32_t bad = 0;
 	for (uint32_t j = 0; j < T; ++j) {
 		WV_MARK("dec_plane_type");
-		if (bad)
-			continue;
 		uint32_t type = j < 8 ? (head >> (4 * j)) & 15 : (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
 		if (type == PLANE_SAME) { // (:1567-1583)
-			if (p >= end)
-				bad = 1;
-			else {
-				U32 v = bytes_splat(lds_ld8(win, U32(p)));
-				store_plane_word(lds, L.img, T, j, v, (lane >> 2) < U32(lines));
-				p += 1;
-			}
+			U32 v = bytes_splat(lds_ld8(win, U32(p)));
+			store_plane_word(lds, L.img, T, j, v, (lane >> 2) < U32(lines));
+			p += 1;
 		}
 		else if (type == PLANE_RAW && full) { // (:1553-1565)
-			if (end - p < 256)
-				bad = 1;
-			else {
-				store_plane_word(lds, L.img, T, j, lds_ld32_unaligned(win, U32(p) + lane * 4u), pred_all(true));
-				p += 256;
-			}
+			store_plane_word(lds, L.img, T, j, lds_ld32_unaligned(win, U32(p) + lane * 4u), pred_all(true));
+			p += 256;
 		}
-		else if (type == PLANE_NORMAL || (type == PLANE_NORMAL_RLE && full)) {
-			uint32_t n = decode_plane(lds, L, T, j, type, p, end - p, lines);
-			if (n == DEC_ERROR)
-				bad = 1;
-			else
-				p += n;
-		}
+		else if (type == PLANE_NORMAL || (type == PLANE_NORMAL_RLE && full))
+			p += decode_plane(lds, L, T, j, type, p, end - p, lines);
 		else
 			bad = 1; // (:1854-1855, 1779-1780)
 	}
 	wave_sync();
-	return bad ? DEC_ERROR : p - cur;
+	return (bad || p > end) ? DEC_ERROR : p - cur;
 }
 
 } // namespace codec

@@ -381,12 +381,17 @@ WV_HD uint32_t max_tail_bytes(uint32_t T) { return 280 * T + header_bytes(T) + 2
 // window size: room for the largest block plus a few KiB so that small blocks are decoded several per refill
 WV_HD uint32_t window_bytes(uint32_t T) { return align16(max_tail_bytes(T) + 2048 + 32); }
 
+// The decoder checks the bytes a block consumed once per block, not before every read: a block whose first byte is in
+// the window reads at most hs + T*(8 + 18 + 16*18) + 16 bytes from there whatever the stream contains, so that much LDS
+// has to follow the window's buffer (the image and some padding behind it; stale bytes are harmless).
+WV_HD uint32_t max_block_reach(uint32_t T) { return header_bytes(T) + T * 314 + 32; }
 WV_HD DecLayout make_dec_layout(uint32_t T)
 {
 	DecLayout L;
 	L.win = 0;
 	L.img = window_bytes(T) + 32;
-	L.total = align16(L.img + 256 * T + 32);
+	const uint32_t after = 256 * T + 32;
+	L.total = align16(L.img + (after > max_block_reach(T) ? after : max_block_reach(T)));
 	return L;
 }
 
