@@ -223,3 +223,21 @@ def test_reference_library_decodes_gpu_frames(lib, ctx):
         assert np.array_equal(back, data)
         r2, back2 = gpu_decompress(lib, ctx, out[:rr], T, data.nbytes)
         assert r2 == data.nbytes and np.array_equal(back2, data)
+
+
+@pytest.mark.parametrize("T", [2, 4])
+def test_block_pairs_many_seeds(lib, ctx, oracle, T):
+    """The int16 / int32 encoder analyses and writes consecutive blocks in pairs, with mini-LZ attempts sequenced in
+    between (superblock_codec.h, encode_run): many seeds of data whose blocks differ in the number of constant planes and
+    in whether the mini-LZ applies, at sizes with odd and even block counts per run and short last superblocks."""
+    per_sb = 131072 // (256 * T) * 256
+    for seed in range(24):
+        kind = ("mixed", "lzmix", "burst")[seed % 3]
+        n = per_sb * (1 + seed % 3) + (seed * 7919) % per_sb + (seed % 5) * 17
+        data = generate(kind, T, n, 1000 + seed)
+        r1, ref = oracle_compress(oracle, data, T, 1)
+        r2, frame = gpu_compress(lib, ctx, data, T, 1)
+        assert r1 == r2, (kind, seed, n)
+        assert np.array_equal(ref, frame), (kind, seed, n)
+        r3, back = gpu_decompress(lib, ctx, frame, T, data.nbytes)
+        assert r3 == data.nbytes and np.array_equal(back, data), (kind, seed, n)
