@@ -1501,6 +1501,9 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	// -- a truncated stream cannot satisfy that (block_compress.h:1560, 1575, 1591-1598, 1642).  Returns from inside the
 	// loop would cost a dozen scalar instructions of exit bookkeeping per plane on every block's critical path.
 	uint32_t bad = 0;
+#ifndef WV_HOST_EMULATION
+#pragma unroll 4
+#endif
 	for (uint32_t j = 0; j < T; ++j) {
 		WV_MARK("dec_plane_type");
 		uint32_t type = j < 8 ? (head >> (4 * j)) & 15 : (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
