@@ -192,7 +192,7 @@ struct stenos_context_s {
 	DevBuf chain;                                    // fused path: ticket counter + one chained-scan word per superblock
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
-	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [24,32) scan carry, [64,320) override payload
+	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) int32 plane probe, [24,32) scan carry, [64,320) override payload
 	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage; // host staging of the strategy layer
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
@@ -403,7 +403,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 		if (stenos_k_launch_init(misc, header, ctx->chain.as<uint64_t>(), s_fused + 2, j.sb_off, s_fused + 8, stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 		ctx->mark(0, stream);
-		if (stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, stream) != hipSuccess)
+		if (stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, (uint32_t*)(misc + 20), stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 		ctx->mark(1, stream);
 	}

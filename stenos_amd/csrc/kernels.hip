@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint
 		*(uint64_t*)misc = first_off;
 		*(uint32_t*)(misc + 12) = 0u;
 		*(uint32_t*)(misc + 16) = 0xFFFFFFFFu;
+		*(uint32_t*)(misc + 20) = 0u; // probe_planes' count
 		*(uint64_t*)(misc + 24) = first_off;
 	}
 	for (uint64_t k = i; k < n1; k += step)
@@ -65,6 +66,21 @@ __global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint
 	for (uint64_t k = i; k < n2; k += step)
 		z2[k] = 0;
 }
+
+// ---- which block loop suits the data (int32) ----------------------------------------------------------------
+// The slot encoder wins when blocks have at most two non-constant planes (it analyses and writes them in pairs), the
+// plane-group loop when they have three or four (floats, noise).  PROBE_SAMPLES blocks spread over the input are
+// looked at; *busy counts those with three or four.  Two instantiations of the fused kernel are launched and the one
+// the count does not ask for returns at once: one kernel with both loops would be large enough to slow down either.
+constexpr uint32_t PROBE_SAMPLES = 64;
+__global__ __launch_bounds__(64) void probe_planes(const uint8_t* __restrict__ src, uint64_t nfull, uint32_t* __restrict__ busy)
+{
+	const uint64_t b = nfull / PROBE_SAMPLES * blockIdx.x;
+	const SameScan s = scan_same_raw(load_raw_block(src + b * 1024ull, 4), 4);
+	if (threadIdx.x == 0 && s.nact >= 3)
+		atomicAdd(busy, 1u);
+}
+__device__ inline bool probe_says_groups(const uint32_t* busy) { return *(const volatile uint32_t*)busy * 2u > PROBE_SAMPLES; }
 
 // ---- fused path -----------------------------------------------------------------------------------------
 // Frame offsets of the superblocks are produced while the encoders run.  Every workgroup publishes the bytes its
@@ -177,10 +193,15 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 // Workgroup 0: the scanner.  Every other workgroup: FUSED_WAVES wavefronts that take FUSED_TICKETS superblocks one
 // after the other -- encode (each wave a run of consecutive blocks into its staging stream), publish the size,
 // then store the previous superblock at its offset (pipeline.h, fused_store).
-template <uint32_t TT>
+// GROUPS (int32 only): the instantiation with the plane-group loop; it and its twin look at the probe's count (busy) and
+// the one that is not wanted returns.
+template <uint32_t TT, bool GROUPS>
 __global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
-									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry, uint32_t dbg)
+									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry, uint32_t dbg,
+									const uint32_t* __restrict__ busy)
 {
+	if (TT == 4 && probe_says_groups(busy) != GROUPS)
+		return;
 	if (blockIdx.x == 0) {
 		if (threadIdx.x < 64)
 			chain_scanner(j, nsb, size, carry);
@@ -208,7 +229,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJ
 #ifdef STENOS_EXP_STATS
 			const uint64_t te = __builtin_readcyclecounter();
 #endif
-			const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w);
+			const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w, !GROUPS);
 			if ((threadIdx.x & 63u) == 0)
 				runs[w] = n;
 #ifdef STENOS_EXP_STATS
@@ -453,31 +474,42 @@ hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1,
 	return hipGetLastError();
 }
 
-template <uint32_t TT>
-static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
+template <uint32_t TT, bool GROUPS>
+static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, const uint32_t* busy,
+				 hipStream_t stream)
 {
 	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 64;
-	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT, GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
 	const uint32_t grid = (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS) + 1; // + the scanner
-	hipLaunchKernelGGL(encode_superblocks<TT>, dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
-			   ticket, carry, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
+	hipLaunchKernelGGL((encode_superblocks<TT, GROUPS>), dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
+			   ticket, carry, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u, busy);
 	return hipGetLastError();
 }
 
 // Superblocks [0, nsb) of the job, all of them bps full blocks with room for any encoding.  desc: nsb zeroed words,
 // ticket: one zeroed word, j.sb_off[0, nsb] zeroed, stage: stenos_k_fused_stage_bytes(); *carry receives the frame
-// offset behind them.
-hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
+// offset behind them.  busy: a zeroed word (init_job clears it) for the int32 probe.
+hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, uint32_t* busy,
+					hipStream_t stream)
 {
 	if (nsb == 0)
 		return hipSuccess;
 	switch (j.T) {
-		case 2: return launch_fused_t<2>(j, nsb, stage, desc, ticket, carry, stream);
-		case 4: return launch_fused_t<4>(j, nsb, stage, desc, ticket, carry, stream);
-		case 8: return launch_fused_t<8>(j, nsb, stage, desc, ticket, carry, stream);
-		default: return launch_fused_t<0>(j, nsb, stage, desc, ticket, carry, stream);
+		case 2: return launch_fused_t<2, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
+		case 4: {
+			// sample the planes when the blocks can be loaded 16 bytes at a time (the slot encoder copes with any alignment)
+			const char* force = getenv("STENOS_EXP_INT32_LOOP"); // experiments: "slots" / "groups"
+			if (force && force[0] == 'g')
+				hipMemsetAsync(busy, 0xFF, 4, stream);
+			else if (!force && ((uintptr_t)j.src & 15u) == 0 && nsb * j.bps >= PROBE_SAMPLES)
+				hipLaunchKernelGGL(probe_planes, dim3(PROBE_SAMPLES), dim3(64), 0, stream, j.src, nsb * j.bps, busy);
+			hipError_t e = launch_fused_t<4, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
+			return e != hipSuccess ? e : launch_fused_t<4, true>(j, nsb, stage, desc, ticket, carry, busy, stream);
+		}
+		case 8: return launch_fused_t<8, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
+		default: return launch_fused_t<0, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
 	}
 }
 // the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)

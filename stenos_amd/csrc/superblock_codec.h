@@ -151,12 +151,14 @@ WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 // `nblocks` full blocks at src -> their encodings, back to back, at stage (16-byte aligned, room for
 // nblocks * max_block_bytes(T) + 16).  Ample capacity is assumed (the mini-LZ is always tried), which is
 // what the reference does for every superblock but the ones at the very end of a tight buffer.
-WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage)
+// slots: bytesoftype 2 and 4 go through the plane slots (two blocks per pass); false: the plane-group loop at the bottom,
+// which is the shorter way for int32 data whose blocks have three or four non-constant planes (kernels.hip, probe_planes).
+WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true)
 {
 	RunStream rs;
 	rs.base = stage;
 	rs.pos = 0;
-	if (T == 2 || T == 4) {
+	if (slots && (T == 2 || T == 4)) {
 		// Planes in slots (block_codec.h, analyse_slots): a block whose non-constant planes leave two slots free is
 		// analysed together with its successor when that one fits into the rest.
 		const uint32_t bs = 256 * T;

@@ -82,6 +82,8 @@ size_t emul_block_decompress(const uint8_t* src, size_t csize, size_t T, size_t 
 // resolve_frame, host zstd for a tiny last superblock, pack_frame), one "workgroup" after the other.
 
 static int g_fused = 1;
+static int g_slots = 1; // 0: the plane-group loop of encode_run also for bytesoftype 2 and 4 (the fused kernel's GROUPS twin)
+void emul_set_slots(int on) { g_slots = on; }
 static size_t g_last_fused = 0;
 void emul_set_fused(int on) { g_fused = on; }
 size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last frame sent through the fused path
@@ -165,7 +167,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 			for (uint32_t w = 0; w < FUSED_WAVES; ++w) {
 				uint32_t b0, b1;
 				fused_run_range(j.bps, w, &b0, &b1);
-				run_size[w] = encode_run(wlds + w * L.total, L, j.T, src + (s * j.bps + b0) * bs, b1 - b0, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
+				run_size[w] = encode_run(wlds + w * L.total, L, j.T, src + (s * j.bps + b0) * bs, b1 - b0, stage + (s * FUSED_WAVES + w) * (size_t)run_cap, g_slots != 0);
 				if (run_size[w] + 48 > run_cap)
 					return (size_t)-1;
 			}

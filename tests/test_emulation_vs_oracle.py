@@ -30,6 +30,8 @@ def emul():
     lib.emul_copy_g2g_wide.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.emul_set_fused.restype = None
     lib.emul_set_fused.argtypes = [c_int]
+    lib.emul_set_slots.restype = None
+    lib.emul_set_slots.argtypes = [c_int]
     return lib
 
 
@@ -135,6 +137,27 @@ def test_frame_pipeline_and_capacity_rules(oracle, emul, T, fused):
     assert (fused_superblocks > 0) == bool(fused)
     if T % 4 == 0:
         assert replayed > 0, "no case exercised the capacity replay"
+
+
+def test_fused_path_plane_group_loop_for_int32(oracle, emul):
+    """The twin of the fused kernel that the plane probe selects for int32 data with three or four non-constant planes
+    per block (kernels.hip, probe_planes) runs encode_run without the slots."""
+    from _libs import oracle_compress
+
+    emul.emul_set_fused(1)
+    emul.emul_set_slots(0)
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    try:
+        per = 131072 // (256 * 4) * 256
+        for kind in KINDS:
+            data = generate(kind, 4, 2 * per + 300, 21)
+            r1, f1 = oracle_compress(oracle, data, 4, 1)
+            out = np.zeros(r1 + 5000, dtype=np.uint8)
+            r2 = emul.emul_compress_frame(np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes, 1)
+            assert r2 == r1 and np.array_equal(out[:r2], f1), kind
+    finally:
+        emul.emul_set_slots(1)
 
 
 @pytest.mark.parametrize("T", [2, 4])
