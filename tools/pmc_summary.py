@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 input_bytes = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0 * (1 << 30)  # bytes of the profiled workload
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
+full_names = collections.defaultdict(lambda: collections.defaultdict(int))  # base name -> counter -> {full kernel name: rows}
 # gpurun merges new outputs into the local directory: keep only the newest collection of every pass
 newest = {}
 for p in glob.glob(os.path.join(ROOT, "gpurun_out/pmc/p*/*/*_counter_collection.csv")):
@@ -26,10 +27,15 @@ for p in sorted(newest.values()):
             continue
         name = k.split("::")[1].split("(")[0].split("<")[0]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        full_names[name][(r["Counter_Name"], k)] += 1
 out = {}
 for name, cs in agg.items():
-    out[name] = {c: sum(v) / len(v) for c, v in cs.items()}
-    out[name]["launches_averaged"] = len(next(iter(cs.values())))
+    # int32 launches two instantiations of encode_superblocks per call (one returns at once): their
+    # counters add up to one launch, so the divisor is the number of rows of one instantiation
+    first = next(iter(cs))
+    launches = max(n for (c, k), n in full_names[name].items() if c == first)
+    out[name] = {c: sum(v) / launches for c, v in cs.items()}
+    out[name]["launches_averaged"] = launches
 res = {"source": "rocprofv3 --pmc (tools/pmc_run.sh), bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-entropy", "kernels": out}
 # On this pool the per-dispatch counters cover only a fraction of the chip's shader engines (it varies from run
 # to run: 7/16, 0.55 ... observed), for every kernel and counter alike.  decode_superblocks stores exactly the
