@@ -241,3 +241,18 @@ def test_block_pairs_many_seeds(lib, ctx, oracle, T):
         assert np.array_equal(ref, frame), (kind, seed, n)
         r3, back = gpu_decompress(lib, ctx, frame, T, data.nbytes)
         assert r3 == data.nbytes and np.array_equal(back, data), (kind, seed, n)
+
+
+def test_int32_block_loops_agree(lib, ctx, oracle, monkeypatch):
+    """int32 has two block loops in the fused kernel, picked by a probe of the data (kernels.hip, probe_planes): forced
+    either way (STENOS_EXP_INT32_LOOP) they must write the oracle's frame for data of both kinds, and so must the probe."""
+    for kind, n in (("rand12", 700_001), ("sine", 500_003), ("mixed", 600_001), ("lzmix", 400_003), ("rand", 300_001)):
+        data = generate(kind, 4, n, 17)
+        r1, ref = oracle_compress(oracle, data, 4, 1)
+        for loop in ("slots", "groups", None):
+            if loop is None:
+                monkeypatch.delenv("STENOS_EXP_INT32_LOOP", raising=False)
+            else:
+                monkeypatch.setenv("STENOS_EXP_INT32_LOOP", loop)
+            r2, frame = gpu_compress(lib, ctx, data, 4, 1)
+            assert r1 == r2 and np.array_equal(ref, frame), (kind, loop)
