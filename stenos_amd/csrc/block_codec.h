@@ -498,11 +498,6 @@ WV_FN void analyse_slots(Lds lds, const Layout& L, uint32_t nslots)
 	wave_sync();
 	analyse_stage2(lds, L, 0, nslots, true, 16, nullptr);
 }
-// where emit_planes finds the rows of a block that was analysed in slots
-struct SlotMap {
-	uint32_t first; // first byte of every plane, packed
-	U32 nib;        // lane 0: the plane type nibbles of the block
-};
 
 // What the frame assembly needs to know about an encoded block to reproduce the reference's
 // capacity rules (block_compress.h:1214, 1225, 1241; block_compress_partial :984, 994, 1013):
@@ -572,18 +567,13 @@ WV_HD uint32_t plane_offsets_small(uint32_t T, bool full_block, uint32_t lines, 
 
 // Write the planes of an analysed block into the (zeroed) output image starting at byte `base`.
 // tab: the scalar plane table of plane_offsets_small (bytesoftype <= 4) or null (L.plinfo holds it).
-// sm: the block was analysed in slots (tab given, entries type | offset << 8 | slot << 24): the rows and the plane words
-// of a plane are those of its slot (regs is not used), SAME bytes come from sm->first.
-WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs, const uint32_t* tab = nullptr,
-		       const SlotMap* sm = nullptr)
+WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint32_t lines, const PlaneRegs& regs, const uint32_t* tab = nullptr)
 {
 	const U32 lane = lane_id();
 	Lds out = lds + L.out;
 	WV_MARK("emit_nibbles");
 	// plane type nibbles (block_compress.h:1246-1257)
-	if (sm)
-		lds_put_bits(out, U32(base * 8u), sm->nib, lane == U32(0u));
-	else if (tab) {
+	if (tab) {
 		uint32_t nib = 0;
 		for (uint32_t k = 0; k < T; ++k)
 			nib |= (tab[k] & 0xFu) << (4 * k);
@@ -602,18 +592,10 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		const Pred valid = pl < U32(np);
 		U32 lo, hi;
 		U32 pi, type, pbase;
-		if (sm) { // lanes 16p + r: plane p, whose rows are those of slot slotof[p] (constant planes: no rows)
-			pi = row_select4(tab[0], tab[1], tab[2], tab[3]); // type | offset << 8 | slot << 24
-			lds_ld64(lds, U32(L.rowinfo) + ((pi >> 24) * 16u + r) * 8u, lo, hi);
-			type = pi & 0xFFu;
-			pbase = U32(base) + ((pi >> 8) & 0xFFFFu);
-		}
-		else {
-			lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
-			pi = tab ? row_select4(tab[0], tab[1], tab[2], tab[3]) : lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
-			type = pi & 0xFFu;
-			pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
-		}
+		lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
+		pi = tab ? row_select4(tab[0], tab[1], tab[2], tab[3]) : lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
+		type = pi & 0xFFu;
+		pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
 		Pred normal = valid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
 		Pred act = r < U32(lines);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
@@ -627,8 +609,7 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 				  sel(pl == U32(2u), U32((uint32_t)((eqb >> 32) & 0xFFFF)), U32((uint32_t)(eqb >> 48)))));
 		lds_put_bits(out, (pbase + 8u) * 8u, m16, valid & (type == U32(PLANE_NORMAL_RLE)) & (r == U32(0u)));
 		// SAME: the plane's byte; every row has mx == mn so minv is that byte (:747-750)
-		if (!sm)
-			lds_put_small(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
+		lds_put_small(out, pbase * 8u, minv, valid & (type == U32(PLANE_SAME)) & (r == U32(0u)));
 	}
 	// element lanes: row payloads.  Every lane contributes one piece per plane (its 4 raw bytes, its 4
 	// packed values or its rle literals); rle rows add their 4 mask bits.
@@ -640,18 +621,15 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 			cur = load_plane_regs(lds, L.in, T, j);
 		uint32_t pi = tab ? tab[j] : readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
 		uint32_t type = pi & 0xFFu;
-		uint32_t pbase = base + ((pi >> 8) & 0xFFFFu);
-		if (type == PLANE_SAME) {
-			if (sm) // (:747-750); without a slot map the row lanes above have written it
-				lds_put_small(out, U32(pbase * 8u), U32((sm->first >> (8 * j)) & 0xFFu), lane == U32(0u));
+		uint32_t pbase = base + (pi >> 8);
+		if (type == PLANE_SAME)
 			continue;
-		}
-		U32 w = sm ? lds_ld32(lds, U32(slot_image(L, pi >> 24)) + lane * 4u) : fetch_plane_word(lds, L.in, T, j, cur);
+		U32 w = fetch_plane_word(lds, L.in, T, j, cur);
 		if (type == PLANE_RAW) {
 			lds_put_bits(out, (U32(pbase) + lane * 4u) * 8u, w, pred_all(true));
 			continue;
 		}
-		U32 lo = lds_ld32(lds, U32(L.rowinfo + (sm ? pi >> 24 : j) * 128u) + row * 8u);
+		U32 lo = lds_ld32(lds, U32(L.rowinfo + j * 128u) + row * 8u);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
 		U32 rbase = U32(pbase) + (lo >> 16);
 		Pred act = row < U32(lines);
