@@ -1357,12 +1357,29 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 A = sel(e6 | isdelta, U32(0xFu), sel(e7, f, U32(0u)));
 	U32 Bw = sel(e15, rawv, sel(e6, dv, sel(e7, rlev, packed)));
 	U32 outw;
-	if (any(A != U32(0u))) {
+	if (!any(A != U32(0u)))
+		outw = Bw;
+	else if (!any(erle & eact)) {
+		// Only delta rows and absolute rows (no run-length rows: the common shape of slowly varying data).  A delta lane's
+		// bytes are prefix sums of its four deltas plus the last byte before it; that byte is the last byte of the
+		// nearest absolute lane before it plus the deltas in between: two wave scans (sum, position of the last absolute
+		// lane) and one gather instead of six rounds of function composition.
+		const Pred dl = A != U32(0u);
+		U32 p = bytes_add(Bw, Bw << 8);
+		p = bytes_add(p, p << 16); // byte k: d0 + .. + dk
+		const U32 total = sel(dl, p >> 24, U32(0u));
+		const U32 P = wave_incl_scan(total);
+		const U32 start = wave_incl_scan_max(sel(dl, U32(0u), lane + 1u)); // 1 + the last absolute lane up to here, 0: none
+		const U32 sprev = shfl_up(start, 1, 0), Pprev = shfl_up(P, 1, 0);
+		const U32 g = shfl((P & 0xFFFFu) | ((Bw >> 24) << 16), sel(sprev == U32(0u), U32(0u), sprev - 1u));
+		const U32 gP = sel(sprev == U32(0u), U32(0u), g & 0xFFFFu), gB = sel(sprev == U32(0u), U32(0u), g >> 16);
+		const U32 carry = (gB + Pprev - gP) & 0xFFu;
+		outw = sel(dl, bytes_add(p, bytes_splat(carry)), Bw);
+	}
+	else {
 		U32 cin = chain_carry(A, Bw, 63);
 		outw = chain_apply(A, Bw, cin);
 	}
-	else
-		outw = Bw;
 	WV_MARK("dec_plane_store");
 	store_plane_word(lds, L.img, T, j, outw, eact);
 	WV_MARK("dec_plane_end");

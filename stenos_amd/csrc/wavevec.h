@@ -769,6 +769,12 @@ WV_FN uint32_t wave_or(const U32& x)
 	for (int i = 0; i < WAVE; ++i) r |= x.l[i];
 	return r;
 }
+// inclusive prefix maximum over the 64 lanes
+WV_FN U32 wave_incl_scan_max(U32 s)
+{
+	for (int i = 1; i < WAVE; ++i) s.l[i] = s.l[i] > s.l[i - 1] ? s.l[i] : s.l[i - 1];
+	return s;
+}
 // inclusive prefix sum over the 64 lanes
 WV_FN U32 wave_incl_scan(U32 s)
 {
@@ -802,6 +808,17 @@ WV_FN uint32_t wave_or(U32 x)
 	return readlane(x, 0) | readlane(x, 16) | readlane(x, 32) | readlane(x, 48);
 }
 // row_shr 1,2,4,8 with zero fill, then row_bcast:15 (0x142, rows 1 and 3) and row_bcast:31 (0x143, rows 2 and 3)
+// the same DPP pattern with a maximum (lanes without a source read 0, the neutral element for unsigned values)
+WV_FN U32 wave_incl_scan_max(U32 s)
+{
+	s = umax(s, dpp_zero<0x111>(s));
+	s = umax(s, dpp_zero<0x112>(s));
+	s = umax(s, dpp_zero<0x114>(s));
+	s = umax(s, dpp_zero<0x118>(s));
+	s = umax(s, (U32)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false));
+	s = umax(s, (U32)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false));
+	return s;
+}
 WV_FN U32 wave_incl_scan(U32 s)
 {
 	s += dpp_zero<0x111>(s);
