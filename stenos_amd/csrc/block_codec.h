@@ -1244,10 +1244,15 @@ WV_FN U32 chain_carry(const U32& A, const U32& Bw, uint32_t seg_mask)
 	U32 last = chain_apply(A, Bw, U32(0u)) >> 24;
 	U32 f = (sel((A & 0xFu) == U32(0xFu), U32(1u), U32(0u)) << 8) | last;
 	const U32 ident(1u << 8);
-	for (uint32_t d = 1; d <= seg_mask; d <<= 1) {
-		U32 prev = shfl_up(f, d, 1u << 8);
-		prev = sel((lane & U32(seg_mask)) >= U32(d), prev, ident);
-		f = chain_compose(prev, f);
+	if (seg_mask == 63) // whole wave: the DPP scan pattern (no LDS crossbar)
+		for (int step = 0; step < 6; ++step)
+			f = chain_compose(scan_source(f, step, 1u << 8), f);
+	else { // inside the segments (quads: seg_mask 3): the row shifts, cut at the segment starts
+		int step = 0;
+		for (uint32_t d = 1; d <= seg_mask; d <<= 1, ++step) {
+			U32 prev = sel((lane & U32(seg_mask)) >= U32(d), scan_source(f, step, 1u << 8), ident);
+			f = chain_compose(prev, f);
+		}
 	}
 	U32 ex = shfl_up(f, 1, 1u << 8);
 	ex = sel((lane & U32(seg_mask)) == U32(0u), ident, ex);

@@ -769,6 +769,25 @@ WV_FN uint32_t wave_or(const U32& x)
 	for (int i = 0; i < WAVE; ++i) r |= x.l[i];
 	return r;
 }
+// The six data movements of a wave-wide inclusive scan in DPP order (any associative operator): steps 0-3 shift by 1, 2,
+// 4, 8 inside the rows of 16 lanes, step 4 hands the total of rows 0 / 2 (lanes 15 / 47) to rows 1 / 3, step 5 the total of
+// rows 0-1 (lane 31) to rows 2 and 3.  Lanes without a source read `ident`.
+WV_FN U32 scan_source(const U32& x, int step, uint32_t ident)
+{
+	U32 r(ident);
+	for (int i = 0; i < WAVE; ++i) {
+		if (step < 4) {
+			int d = 1 << step;
+			if ((i & 15) >= d) r.l[i] = x.l[i - d];
+		}
+		else if (step == 4) {
+			if ((i >> 4) & 1) r.l[i] = x.l[(i & ~15) - 1];
+		}
+		else if (i >= 32)
+			r.l[i] = x.l[31];
+	}
+	return r;
+}
 // inclusive prefix maximum over the 64 lanes
 WV_FN U32 wave_incl_scan_max(U32 s)
 {
@@ -808,6 +827,18 @@ WV_FN uint32_t wave_or(U32 x)
 	return readlane(x, 0) | readlane(x, 16) | readlane(x, 32) | readlane(x, 48);
 }
 // row_shr 1,2,4,8 with zero fill, then row_bcast:15 (0x142, rows 1 and 3) and row_bcast:31 (0x143, rows 2 and 3)
+// one data movement of a wave-wide inclusive scan (see the host version): row_shr:1/2/4/8, row_bcast:15, row_bcast:31
+WV_FN U32 scan_source(U32 x, int step, uint32_t ident)
+{
+	switch (step) {
+		case 0: return (U32)__builtin_amdgcn_update_dpp((int)ident, (int)x, 0x111, 0xf, 0xf, false);
+		case 1: return (U32)__builtin_amdgcn_update_dpp((int)ident, (int)x, 0x112, 0xf, 0xf, false);
+		case 2: return (U32)__builtin_amdgcn_update_dpp((int)ident, (int)x, 0x114, 0xf, 0xf, false);
+		case 3: return (U32)__builtin_amdgcn_update_dpp((int)ident, (int)x, 0x118, 0xf, 0xf, false);
+		case 4: return (U32)__builtin_amdgcn_update_dpp((int)ident, (int)x, 0x142, 0xa, 0xf, false);
+		default: return (U32)__builtin_amdgcn_update_dpp((int)ident, (int)x, 0x143, 0xc, 0xf, false);
+	}
+}
 // the same DPP pattern with a maximum (lanes without a source read 0, the neutral element for unsigned values)
 WV_FN U32 wave_incl_scan_max(U32 s)
 {
