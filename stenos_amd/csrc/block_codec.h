@@ -1293,7 +1293,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));
 		U32 e = sel(emit, U32(1u), U32(0u));
 		U32 ex = row_excl_scan(e);
-		minslen = readlane(row_add(e), 0);
+		minslen = readlane(ex + e, 15); // the last row's inclusive value is the total
 		minv = lds_ld8(win, U32(cur + nh) + sel(emit, ex, U32(0u)));
 	}
 	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins
@@ -1309,6 +1309,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	Pred isrle = act & ((hdr == U32(6u)) | (hdr == U32(7u)));
 	U32 known = sel(act & !isrle, sel(hdr == U32(15u), U32(16u), (hdr & 7u) * 2u), U32(0u));
 	U32 pre = row_excl_scan(known);
+	const uint32_t totals = readlane(pre + known, 15);
 	U32 rmask(0u), extra(0u);
 	const uint32_t base = cur + nh + minslen;
 	uint32_t todo = (uint32_t)(ballot(isrle) & 0xFFFFu);
@@ -1323,7 +1324,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		extra = extra + sel(r > U32(rr), U32(sz), U32(0u));
 		rle_total += sz;
 	}
-	uint32_t psize = nh + minslen + readlane(row_add(known), 0) + rle_total;
+	uint32_t psize = nh + minslen + (totals & 0xFFFFu) + rle_total;
 	U32 poff = U32(base) + pre + extra;
 
 	WV_MARK("dec_plane_elems");
