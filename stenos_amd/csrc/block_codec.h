@@ -1313,6 +1313,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 rmask(0u), extra(0u);
 	const uint32_t base = cur + nh + minslen;
 	uint32_t todo = (uint32_t)(ballot(isrle) & 0xFFFFu);
+	const bool has_rle = todo != 0, has_raw = (ballot(act & (hdr == U32(15u))) & 0xFFFFu) != 0; // row kinds present: the element view skips what no row needs
 	uint32_t rle_total = 0;
 	while (todo) {
 		uint32_t rr = (uint32_t)__builtin_ctz(todo);
@@ -1331,7 +1332,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	// ---- element view: lane l owns elements 4l..4l+3, its row is l>>2 ----
 	const U32 row = lane >> 2, q = lane & 3u;
 	U32 info = shfl(hdr | (minv << 8) | (poff << 16), row);
-	U32 emask = shfl(rmask, row);
+	U32 emask = has_rle ? shfl(rmask, row) : U32(0u);
 	U32 eh = info & 0xFFu, emin = (info >> 8) & 0xFFu, eoff = info >> 16;
 	Pred eact = row < U32(lines);
 	Pred e15 = eh == U32(15u), e7 = eh == U32(7u), e6 = eh == U32(6u);
@@ -1344,19 +1345,23 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 y = (px & vm) | (((px >> bits) & vm) << 8) | (((px >> (bits * 2u)) & vm) << 16) | (((px >> (bits * 3u)) & vm) << 24);
 	U32 packed = bytes_add(y, bytes_splat(emin));
 	// raw row bytes
-	U32 rawv = lds_ld32_unaligned(win, sel(eact & e15, eoff + q * 4u, U32(0u)));
+	U32 rawv(0u);
+	if (has_raw)
+		rawv = lds_ld32_unaligned(win, sel(eact & e15, eoff + q * 4u, U32(0u)));
 	// rle rows: flags of this lane and its literals
-	U32 f = (emask >> (q << 2)) & 0xFu;
-	U32 litidx = popc((~emask) & ((U32(1u) << (q << 2)) - 1u) & 0xFFFFu);
-	U32 lits = lds_ld32_unaligned(win, sel(eact & erle, eoff + 2u + litidx, U32(0u)));
-	U32 rlev = expand_literals(lits, f);
-
-	// delta-rle rows first rebuild their deltas: d_k = flag ? d_{k-1} : literal, d_{-1} = 0 per row
-	U32 dv = rlev;
-	if (any(eact & e6)) {
-		U32 A6 = sel(e6, f, U32(0u));
-		U32 cin = chain_carry(A6, rlev, 3);
-		dv = sel(e6, chain_apply(A6, rlev, cin), rlev);
+	U32 f(0u), rlev(0u), dv(0u);
+	if (has_rle) {
+		f = (emask >> (q << 2)) & 0xFu;
+		U32 litidx = popc((~emask) & ((U32(1u) << (q << 2)) - 1u) & 0xFFFFu);
+		U32 lits = lds_ld32_unaligned(win, sel(eact & erle, eoff + 2u + litidx, U32(0u)));
+		rlev = expand_literals(lits, f);
+		// delta-rle rows first rebuild their deltas: d_k = flag ? d_{k-1} : literal, d_{-1} = 0 per row
+		dv = rlev;
+		if (any(eact & e6)) {
+			U32 A6 = sel(e6, f, U32(0u));
+			U32 cin = chain_carry(A6, rlev, 3);
+			dv = sel(e6, chain_apply(A6, rlev, cin), rlev);
+		}
 	}
 	// final chain: absolute rows (A=0), delta rows (A=1), rle rows (A = flags)
 	Pred isdelta = !e15 & !erle & (eh >= U32(8u));
@@ -1365,7 +1370,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 outw;
 	if (!any(A != U32(0u)))
 		outw = Bw;
-	else if (!any(erle & eact)) {
+	else if (!has_rle) {
 		// Only delta rows and absolute rows (no run-length rows: the common shape of slowly varying data).  A delta lane's
 		// bytes are prefix sums of its four deltas plus the last byte before it; that byte is the last byte of the
 		// nearest absolute lane before it plus the deltas in between: two wave scans (sum, position of the last absolute
