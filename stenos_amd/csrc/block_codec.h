@@ -753,15 +753,20 @@ WV_FN void emit_batch(Lds lds, const Layout& L, uint32_t T, const BatchPlan& P, 
 	b[1] = bv.y;
 	b[2] = bv.z;
 	b[3] = bv.w;
-	const U32 prev = row_shr(b[3] >> 24, 1, 0);
-	d[0] = bytes_sub(b[0], (b[0] << 8) | prev);
-	for (int k = 1; k < 4; ++k)
-		d[k] = bytes_sub(b[k], (b[k] << 8) | (b[k - 1] >> 24));
 	const Pred is15 = hdr == U32(15u), is7 = hdr == U32(7u), is6 = hdr == U32(6u);
 	const U32 bits = hdr & 7u;
 	const Pred rawrow = israw | (normal & is15);
 	const Pred packed = normal & !is15 & !is7 & !is6 & (bits != U32(0u));
 	const Pred rle = normal & (is7 | is6);
+	const bool any_rle = any(rle);
+	if (any_rle || any(packed & (hdr >= U32(8u)))) { // no delta-coded or run-length row: nobody needs the deltas
+		const U32 prev = row_shr(b[3] >> 24, 1, 0);
+		d[0] = bytes_sub(b[0], (b[0] << 8) | prev);
+		for (int k = 1; k < 4; ++k)
+			d[k] = bytes_sub(b[k], (b[k] << 8) | (b[k - 1] >> 24));
+	}
+	else
+		d[0] = d[1] = d[2] = d[3] = U32(0u);
 	const U32 rbase = sel(israw, pbase + r * 16u, pbase + (lo >> 16));
 	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each
 	const Pred usedelta = hdr >= U32(8u);
@@ -779,7 +784,7 @@ WV_FN void emit_batch(Lds lds, const Layout& L, uint32_t T, const BatchPlan& P, 
 	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
 	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
-	if (any(rle)) {
+	if (any_rle) {
 		U32 f16(0u), lp = rbase + 2u;
 		for (int k = 0; k < 4; ++k) {
 			const U32 pd = k ? (d[k - 1] >> 24) : U32(0u);
