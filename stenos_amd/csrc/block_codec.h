@@ -1518,19 +1518,23 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	for (uint32_t j = 0; j < T; ++j) {
 		WV_MARK("dec_plane_type");
 		uint32_t type = j < 8 ? (head >> (4 * j)) & 15 : (win_u8(win, cur + (j >> 1)) >> (4 * (j & 1))) & 15;
-		if (type == PLANE_SAME) { // (:1567-1583)
+		if (type >= PLANE_NORMAL) { // two tests per plane whatever its type
+			if (type == PLANE_NORMAL || (type == PLANE_NORMAL_RLE && full))
+				p += decode_plane(lds, L, T, j, type, p, end - p, lines);
+			else
+				bad = 1; // (:1854-1855, 1779-1780)
+		}
+		else if (type == PLANE_SAME) { // (:1567-1583)
 			U32 v = bytes_splat(lds_ld8(win, U32(p)));
 			store_plane_word(lds, L.img, T, j, v, (lane >> 2) < U32(lines));
 			p += 1;
 		}
-		else if (type == PLANE_RAW && full) { // (:1553-1565)
+		else if (full) { // RAW (:1553-1565)
 			store_plane_word(lds, L.img, T, j, lds_ld32_unaligned(win, U32(p) + lane * 4u), pred_all(true));
 			p += 256;
 		}
-		else if (type == PLANE_NORMAL || (type == PLANE_NORMAL_RLE && full))
-			p += decode_plane(lds, L, T, j, type, p, end - p, lines);
 		else
-			bad = 1; // (:1854-1855, 1779-1780)
+			bad = 1;
 	}
 	wave_sync();
 	return (bad || p > end) ? DEC_ERROR : p - cur;
