@@ -411,13 +411,13 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 	const uint32_t wcap = window_bytes(T);
 	const uint32_t mis = (uint32_t)((uintptr_t)src & 15u); // the window is filled from the 16-byte aligned address below src
 	const uint8_t* abase = src - mis;
-	uint32_t wstart = 0, wfill = 0; // window holds abase[wstart, wstart + wfill)
+	uint32_t wstart = 0, wfill = 0, wend = 0; // window holds abase[wstart, wend), wend = wstart + wfill
 	uint32_t consumed = 0;          // payload bytes consumed so far
 
 	auto ensure = [&](uint32_t need) {
 		// make payload bytes [consumed, consumed + need) resident (need already clipped to the payload)
-		uint32_t a = consumed + mis; // offset from abase
-		if (a >= wstart && a + need <= wstart + wfill)
+		uint32_t a = consumed + mis; // offset from abase; never below wstart: the window only moves forward with it
+		if (a + need <= wend)
 			return;
 		const uint32_t nstart = a & ~15u;
 		const uint32_t endoff = csize + mis;
@@ -440,6 +440,7 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 		}
 		wstart = nstart;
 		wfill = nfill;
+		wend = nstart + nfill;
 		if (nfill > keep)
 			copy_g2l(lds, L.win + keep, abase + wstart + keep, nfill - keep);
 		wave_sync();
