@@ -84,6 +84,16 @@ size_t emul_block_decompress(const uint8_t* src, size_t csize, size_t T, size_t 
 static int g_fused = 1;
 static int g_slots = 1; // 0: the plane-group loop of encode_run also for bytesoftype 2 and 4 (the fused kernel's GROUPS twin)
 void emul_set_slots(int on) { g_slots = on; }
+// decoder LDS layout (superblock_codec.h): out = { window offset, image offset, total, window capacity, reach of one block }
+void emul_dec_layout(size_t T, uint32_t* out)
+{
+	const DecLayout L = make_dec_layout((uint32_t)T);
+	out[0] = L.win;
+	out[1] = L.img;
+	out[2] = L.total;
+	out[3] = window_bytes((uint32_t)T);
+	out[4] = max_block_reach((uint32_t)T);
+}
 static size_t g_last_fused = 0;
 void emul_set_fused(int on) { g_fused = on; }
 size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last frame sent through the fused path

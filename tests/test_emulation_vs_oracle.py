@@ -178,3 +178,23 @@ def test_fused_path_with_misaligned_source(oracle, emul, T):
             out = np.zeros(r1 + 5000, dtype=np.uint8)
             r2 = emul.emul_compress_frame(np_ptr(buf) + off, T, data.nbytes, np_ptr(out), out.nbytes, 1)
             assert r2 == r1 and np.array_equal(out[:r2], f1), (kind, off)
+
+
+def test_decoder_lds_covers_the_reach_of_an_unchecked_block(emul):
+    """The decoder checks the bytes a block consumed once per block (block_codec.h, decode_block), so whatever a block
+    whose first byte lies inside the window can read must be inside the wave's LDS allocation, and the image must fit."""
+    import ctypes
+
+    emul.emul_dec_layout.restype = None
+    emul.emul_dec_layout.argtypes = [c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+    for T in list(range(1, 65)):
+        out = (ctypes.c_uint32 * 5)()
+        emul.emul_dec_layout(T, out)
+        win, img, total, wcap, reach = list(out)
+        hs = (T + 1) // 2
+        # worst case per plane: 8 header bytes + 18 (mask16 + 16 mins) + 16 rows of 18 bytes, + a 16-byte read at the end
+        assert reach >= hs + T * (8 + 18 + 16 * 18) + 16, T
+        assert win == 0 and img >= wcap + 16, T
+        assert total >= wcap + reach, T          # a block starting at the window's last byte stays inside
+        assert total >= img + 256 * T, T         # the decoded block
+        assert total <= 64 * 1024, T             # one workgroup's limit
