@@ -874,7 +874,9 @@ WV_HD bool lz_precheck_passes(uint32_t T, uint32_t distinct, uint32_t max_size)
 {
 	const uint32_t B = lz_width(T), nq = lz_precheck_values(T);
 	const uint32_t lower = nq / 8 + nq * B - (nq - distinct) * (B - 1);
-	return !(lower > max_size || (double)lower > (double)max_size * 0.4);
+	// the reference compares doubles, lower > max_size * 0.4 (lz_compress.h:226); for these small integers that is
+	// 5 * lower > 2 * max_size: the product is exact when max_size is a multiple of 5 and at least 0.2 away from an integer otherwise
+	return !(lower > max_size || 5 * lower > 2 * max_size);
 }
 // distinct hash keys among the first nq values of the block at L.in; uses the first KiB of the image (not L.lz)
 WV_FN uint32_t lz_distinct_keys(Lds lds, const Layout& L, uint32_t T)
@@ -1093,7 +1095,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 			if (produced > max_size) // (:221-223)
 				return 0;
 			if (!once && i > quarter) { // (:224-229)
-				if ((double)produced > (double)max_size * 0.4)
+				if (5 * produced > 2 * max_size) // produced > max_size * 0.4 in doubles, see lz_precheck_passes
 					return 0;
 				once = true;
 			}

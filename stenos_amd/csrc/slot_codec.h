@@ -1,0 +1,388 @@
+// slot_codec.h -- the block encoder for bytesoftype 2 and 4, one pass on row lanes.
+//
+// Planes whose 256 bytes are all equal (SAME) need no analysis and a block of 16-bit elements has only two planes, so
+// the planes that do need it are written, in plane order, to up to four "slots" of 256 bytes in LDS; the slots may come
+// from two consecutive blocks (a batch).  Lane 16*s + r then owns row r of slot s from the first load to the last
+// store: it reads its 16 bytes once, measures them (block_compress.h:385-535), takes the row's decisions, learns
+// where the plane goes in the image and writes header nibble, minimum and payload (block_compress.h:739-806) without
+// handing anything to another lane through memory.  Cross-row quantities (previous byte, previous minimum, plane totals,
+// offsets) move with DPP inside the 16-lane rows, which are exactly the slots.
+//
+// Everything is computed on biased bytes (x ^ 0x80): the reference's signed comparisons (_mm_min_epi8, :407-411) become
+// unsigned ones, and "value - minimum" of a row needs no borrow handling between the packed bytes.
+#pragma once
+#include "block_codec.h"
+
+namespace codec {
+
+constexpr uint32_t SLOT2_BYTES = 256; // lane 16*s + r reads LDS bytes [16*lane, 16*lane + 16) of the slot area: no bank conflicts
+WV_HD uint32_t slot2_area(const Layout& L) { return L.aux; }
+
+// ---- element lanes: a block in registers -> its non-constant planes in slots slot, slot + 1, ... ---------------------
+// Byte k of the OR over all elements of (element ^ first element) is non-zero exactly when plane k is not constant
+// (block_compress.h:396, 406, 415-418).
+WV_FN SameScan scan_same_fast(const RawBlock& b, uint32_t T)
+{
+	SameScan s;
+	U32 x;
+	if (T == 2) {
+		const uint32_t e0 = readlane(b.e.x, 0) & 0xFFFFu;
+		const U32 e(e0 * 0x00010001u);
+		x = (b.e.x ^ e) | (b.e.y ^ e);
+		x = x | (x >> 16);
+		s.first = e0;
+	}
+	else {
+		const uint32_t e0 = readlane(b.e.x, 0);
+		const U32 e(e0);
+		x = ((b.e.x ^ e) | (b.e.y ^ e)) | ((b.e.z ^ e) | (b.e.w ^ e));
+		s.first = e0;
+	}
+	s.act = mask_nonzero(ballot((x & 0xFFu) != U32(0u))) | (mask_nonzero(ballot((x & 0xFF00u) != U32(0u))) << 1);
+	if (T == 4)
+		s.act |= (mask_nonzero(ballot((x & 0xFF0000u) != U32(0u))) << 2) | (mask_nonzero(ballot((x & 0xFF000000u) != U32(0u))) << 3);
+	s.nact = (uint32_t)__builtin_popcount(s.act);
+	return s;
+}
+
+WV_FN void write_slots_fast(Lds lds, const Layout& L, const RawBlock& b, uint32_t T, uint32_t act, uint32_t slot)
+{
+	const U32 a = U32(slot2_area(L)) + lane_id() * 4u;
+	if (T == 2) {
+		if (act & 1u) {
+			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(b.e.y, b.e.x, 0x06040200u), pred_all(true));
+			++slot;
+		}
+		if (act & 2u)
+			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(b.e.y, b.e.x, 0x07050301u), pred_all(true));
+		return;
+	}
+	// 4 x 4 byte transpose in two steps; a step is skipped when none of its planes is wanted
+	if (act & 3u) {
+		const U32 t0 = perm_bytes(b.e.y, b.e.x, 0x05010400u), t2 = perm_bytes(b.e.w, b.e.z, 0x05010400u); // bytes 0 and 1 of two elements each
+		if (act & 1u) {
+			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t2, t0, 0x05040100u), pred_all(true));
+			++slot;
+		}
+		if (act & 2u) {
+			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t2, t0, 0x07060302u), pred_all(true));
+			++slot;
+		}
+	}
+	if (act & 12u) {
+		const U32 t1 = perm_bytes(b.e.y, b.e.x, 0x07030602u), t3 = perm_bytes(b.e.w, b.e.z, 0x07030602u); // bytes 2 and 3
+		if (act & 4u) {
+			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t3, t1, 0x05040100u), pred_all(true));
+			++slot;
+		}
+		if (act & 8u)
+			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t3, t1, 0x07060302u), pred_all(true));
+	}
+}
+
+// Distinct hash keys among the first 80 values of a block of bytesoftype 4 that is still in registers (lanes 0..19
+// hold them): the first rejection test of the mini-LZ (block_codec.h, lz_precheck_passes).  hash_val
+// (lz_compress.h:47-56) keeps the low byte of value * 2654435761, which only depends on the value's low byte.  Every
+// value writes a tag of its own into table[key]; after all writes each key holds exactly one tag, so the values that
+// find their own tag back are as many as there are distinct keys.  No zeroing, no atomics.
+WV_FN uint32_t lz_distinct_keys_fast(Lds lds, const Layout& L, const U128& e)
+{
+	uint32_t distinct = 0;
+	lanes_below(lz_precheck_values(4) / 4, [&](const Pred& in) {
+		const U32 lane = lane_id();
+		const U32 v[4] = { e.x, e.y, e.z, e.w };
+		U32 addr[4];
+		for (int k = 0; k < 4; ++k) {
+			addr[k] = U32(L.out) + (mul24(v[k], U32(0xB1u * 4u)) & 0x3FCu);
+			lds_st32(lds, addr[k], lane + U32(64u * (uint32_t)k), in);
+		}
+		wave_sync();
+		for (int k = 0; k < 4; ++k)
+			distinct += (uint32_t)__builtin_popcountll(ballot(in & (lds_ld32(lds, addr[k]) == lane + U32(64u * (uint32_t)k))));
+	});
+	wave_sync();
+	return distinct;
+}
+
+// ---- row lanes ---------------------------------------------------------------------------------------------------------
+
+// per-byte a - p (mod 256) of biased operands, biased result: (a ^ H) - (p ^ H) = a - p, and bias the difference again
+WV_FN U32 biased_sub(const U32& a, const U32& p)
+{
+	const U32 H(0x80808080u);
+	return ((a | H) - (p & ~H)) ^ ((a ^ p) & H);
+}
+// (hi << 8) | (lo >> 24): the dword that starts one byte before hi
+WV_FN U32 prev_bytes(const U32& hi, const U32& lo) { return (hi << 8) | (lo >> 24); }
+
+// number of non-zero bytes among the 16 bytes x[0..3]
+WV_FN U32 count_nonzero16(const U32* x)
+{
+	const U32 M(0x7f7f7f7fu);
+	U32 t[4];
+	for (int k = 0; k < 4; ++k)
+		t[k] = ((x[k] & M) + M) | x[k]; // bit 7 of every byte: the byte is not zero
+	U32 f = t[3] & 0x80808080u;
+	f = ((t[2] >> 1) & 0x40404040u) | f;
+	f = ((t[1] >> 2) & 0x20202020u) | f;
+	f = ((t[0] >> 3) & 0x10101010u) | f;
+	return popc(f);
+}
+// smallest and largest of the 16 bytes s[0..3] (unsigned).  A 16-bit minimum has the smallest high byte, so odd bytes are
+// compared where they are and even bytes after a shift by 8 (whatever follows them in the low byte does not matter).
+WV_FN void range16(const U32* s, U32& mn, U32& mx)
+{
+	U32 e[4];
+	for (int k = 0; k < 4; ++k)
+		e[k] = s[k] << 8;
+	const U32 lo = pk_min_u16(pk_min_u16(pk_min_u16(s[0], s[1]), pk_min_u16(s[2], s[3])), pk_min_u16(pk_min_u16(e[0], e[1]), pk_min_u16(e[2], e[3])));
+	const U32 hi = pk_max_u16(pk_max_u16(pk_max_u16(s[0], s[1]), pk_max_u16(s[2], s[3])), pk_max_u16(pk_max_u16(e[0], e[1]), pk_max_u16(e[2], e[3])));
+	mn = umin(lo >> 16, lo & 0xFFFFu) >> 8;
+	mx = umax(hi >> 16, hi & 0xFFFFu) >> 8;
+}
+// bits needed for v in 0..255 (0 for 0)
+WV_FN U32 bitlen8(const U32& v) { return bitlen((v << 1) | 1u) - 1u; }
+
+// What lane 16*s + r knows about row r of slot s once the slots are analysed.
+struct SlotRows {
+	U32 sb[4];  // the row's 16 bytes, biased
+	U32 sd[4];  // their deltas against the previous byte in plane order (0 before the plane, block_compress.h:399-401), biased
+	U32 hdr;    // row header nibble (:497-503)
+	U32 minb;   // the row's minimum (of the bytes or of the deltas, whichever the row codes), biased
+	U32 poff;   // offset of the row's payload in the plane
+	U32 minpos; // offset of the row's minimum in the plane, when it has one
+	Pred emitmin, eq; // the row writes a minimum; its minimum equals that of the row above (bit of the mins-rle mask)
+	U32 type, size;   // of the slot's plane (the same in its 16 lanes)
+};
+
+// Analyse the four slots as full-block planes (rle enabled, raw above 256 bytes: block_compress.h:1110-1111, 1190, 1200-1204).
+WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
+{
+	const U32 lane = lane_id();
+	const U32 H(0x80808080u);
+	WV_MARK("analyse_stage1");
+	{
+		const U128 v = lds_ld128(lds, U32(slot2_area(L)) + lane * 16u);
+		R.sb[0] = v.x ^ H;
+		R.sb[1] = v.y ^ H;
+		R.sb[2] = v.z ^ H;
+		R.sb[3] = v.w ^ H;
+	}
+	// deltas: the byte before a row is the last byte of the row above, before the plane 0
+	const U32 above = row_shr(R.sb[3], 1, 0x80808080u);
+	U32 x[4]; // byte == previous byte  <=>  byte of x is zero (:268-275)
+	{
+		const U32 p0 = prev_bytes(R.sb[0], above);
+		x[0] = R.sb[0] ^ p0;
+		R.sd[0] = biased_sub(R.sb[0], p0);
+		for (int k = 1; k < 4; ++k) {
+			const U32 p = prev_bytes(R.sb[k], R.sb[k - 1]);
+			x[k] = R.sb[k] ^ p;
+			R.sd[k] = biased_sub(R.sb[k], p);
+		}
+	}
+	const U32 c1 = count_nonzero16(x) + 2u; // rle cost: 2 + 16 - popcnt(mask)  (:464-467)
+	// delta == previous delta, the delta before a row's first column being 0 (:248-255, 449-458); the bias cancels
+	x[0] = R.sd[0] ^ ((R.sd[0] << 8) | 0x80u);
+	for (int k = 1; k < 4; ++k)
+		x[k] = R.sd[k] ^ prev_bytes(R.sd[k], R.sd[k - 1]);
+	const U32 c2 = count_nonzero16(x) + 2u; // (:470-472)
+	U32 mn, mx, dmn, dmx;
+	range16(R.sb, mn, mx);
+	range16(R.sd, dmn, dmx);
+
+	WV_MARK("analyse_stage2");
+	U32 b0 = bitlen8(mx - mn), b1 = bitlen8(dmx - dmn);
+	b0 = sel(b0 >= U32(6u), U32(8u), b0); // 7 -> 8 (:336-339), header 6 is reserved for delta-rle (:422)
+	b1 = sel(b1 >= U32(7u), U32(8u), b1);
+	const U32 bits = umin(b0, b1);
+	const Pred type0 = b0 == bits; // ties go to frame-of-reference (:423-427)
+	R.minb = sel(type0, mn, dmn);
+	U32 cost = bits * 2u + 1u - (bits >> 3); // (:433-435)
+	U32 hdr = sel(type0, b0 + (b0 >> 3) * 7u, b1 + 8u); // (:497-503)
+	const Pred u1 = c1 < cost; // strictly smaller wins
+	cost = sel(u1, c1, cost);
+	hdr = sel(u1, U32(7u), hdr);
+	const Pred u2 = c2 < cost;
+	cost = sel(u2, c2, cost);
+	hdr = sel(u2, U32(6u), hdr);
+	R.hdr = hdr;
+	const Pred nomin = (hdr == U32(15u)) | ((hdr & 14u) == U32(6u));
+	R.eq = R.minb == row_shr(R.minb, 1, 0x80u); // the minimum before row 0 counts as 0 (:483)
+	const U32 tot = row_add(cost | sel(nomin, U32(1u << 12), U32(0u)) | sel(R.eq, U32(1u << 17), U32(0u)));
+	const U32 sumcost = tot & 0xFFFu, count8 = (tot >> 12) & 31u, eqc = (tot >> 17) & 31u;
+	// mins rle (:478-490): 2 + non-repeated mins < mins that would be written
+	const U32 plain = U32(16u) - count8, packed = U32(18u) - eqc;
+	const Pred minsrle = packed < plain;
+	const U32 minslen = umin(packed, plain);
+	U32 size = sumcost + 8u + minslen - plain; // (:476, 488)
+	const Pred raw = size > U32(256u);
+	R.type = sel(raw, U32(PLANE_RAW), sel(minsrle, U32(PLANE_NORMAL_RLE), U32(PLANE_NORMAL)));
+	R.size = sel(raw, U32(256u), size);
+	const U32 pay = cost - sel(nomin, U32(0u), U32(1u));
+	R.emitmin = (minsrle & !R.eq) | (!minsrle & !nomin);
+	const U32 ex = row_excl_scan(pay | sel(R.emitmin, U32(1u << 16), U32(0u)));
+	R.poff = minslen + 8u + (ex & 0xFFFFu);
+	R.minpos = sel(minsrle, U32(10u), U32(8u)) + (ex >> 16);
+}
+
+// A batch: one block or two consecutive ones whose non-constant planes fill slots 0 .. nslots-1 (block 0 first).
+struct SlotBatch {
+	uint32_t act[2];   // bit k: plane k of the block is not constant
+	uint32_t first[2]; // first element of each block (the bytes of its SAME planes)
+	uint32_t nact0;    // slots of block 0
+	uint32_t nslots;   // slots of both
+	uint32_t nblk;
+	uint32_t full[2];  // sum of the plane sizes of each block (block_compress.h:1189-1207)
+};
+
+// Where the planes go: P.pbase = offset of the slot's plane in its block's encoding, P.k its plane number, P.blk its block.
+struct SlotPlace {
+	U32 pbase, k, blk, act, first;
+	Pred valid;
+};
+WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T)
+{
+	SlotPlace P;
+	const U32 lane = lane_id();
+	const U32 s = lane >> 4;
+	// the slots are the set bits of act[0] | act[1] << 4 in order
+	uint32_t m = B.act[0] | (B.act[1] << 4) | 0xF00u, pos[4]; // (the sentinel bits keep the search defined for unused slots)
+	for (int i = 0; i < 4; ++i) {
+		pos[i] = (uint32_t)__builtin_ctz(m);
+		m &= m - 1u;
+	}
+	const U32 posv = row_select4(pos[0], pos[1], pos[2], pos[3]);
+	P.k = posv & 3u;
+	P.blk = posv >> 2;
+	P.valid = s < U32(B.nslots);
+	// inclusive sums of the plane sizes over the slots (the value of a slot is the same in its 16 lanes)
+	U32 incl = R.size + scan_source(R.size, 4, 0u);
+	incl = incl + scan_source(incl, 5, 0u);
+	const uint32_t p0 = B.nact0 ? readlane(incl, 16u * B.nact0 - 1u) : 0u;
+	const uint32_t pt = B.nslots ? readlane(incl, 16u * B.nslots - 1u) : 0u;
+	B.full[0] = p0 + (T - B.nact0);
+	B.full[1] = B.nblk > 1 ? pt - p0 + (T - (B.nslots - B.nact0)) : 0u;
+	const Pred second = P.blk != U32(0u);
+	P.act = sel(second, U32(B.act[1]), U32(B.act[0]));
+	P.first = sel(second, U32(B.first[1]), U32(B.first[0]));
+	// planes before mine in my block: SAME ones take a byte each, the others are the slots before mine
+	const U32 j = s - sel(second, U32(B.nact0), U32(0u));
+	P.pbase = U32(header_bytes(T)) + (P.k - j) + (incl - R.size - sel(second, U32(p0), U32(0u)));
+	return P;
+}
+
+// OR a value that cannot straddle a dword (a nibble at a nibble-aligned bit position, a byte at a byte-aligned one) into the
+// zeroed image.  Lanes that have nothing to write OR a zero wherever their position points, inside the image's 2 KiB.
+WV_FN void put_small(Lds out, const U32& bitpos, const U32& value, const Pred& p)
+{
+	lds_or32_all(out, (bitpos >> 3) & 0x7FCu, sel(p, value << (bitpos & 31u), U32(0u)));
+}
+// the same for up to 32 bits at any bit position
+WV_FN void put_bits(Lds out, const U32& bitpos, const U32& value, const Pred& p)
+{
+	const U32 a = (bitpos >> 3) & 0x7FCu, sh = bitpos & 31u, v = sel(p, value, U32(0u));
+	lds_or32_all(out, a, v << sh);
+	lds_or32_all(out, a + 4u, sel(sh == U32(0u), U32(0u), v >> (U32(32u) - sh)));
+}
+
+// four values of at most `bits` bits, one per byte of x -> 4*bits bits
+WV_FN U32 pack4v(const U32& x, const U32& bits)
+{
+	const U32 t = (x & 0x00FF00FFu) | (((x >> 8) & 0x00FF00FFu) << bits);
+	return (t & 0xFFFFu) | ((t >> 16) << (bits + bits));
+}
+
+// Write the blocks of the batch into the zeroed image, block i at byte base[i]: type nibbles, SAME bytes, row headers,
+// minima and payloads (block_compress.h:739-806, 1246-1257).
+WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& R, const SlotPlace& P, const SlotBatch& B, uint32_t base0, uint32_t base1)
+{
+	const U32 lane = lane_id();
+	const U32 r = lane & 15u;
+	const U32 H(0x80808080u);
+	Lds out = lds + L.out;
+	const uint32_t hs = header_bytes(T);
+	WV_MARK("emit_nibbles");
+	const Pred second = P.blk != U32(0u);
+	const U32 bbase = sel(second, U32(base1), U32(base0));
+	const U32 pbase = bbase + P.pbase;
+	{
+		// One small write per lane of a slot: lane 0 the plane's type nibble (:1246-1257); lanes 1..3 the bytes of the SAME
+		// planes that follow the plane directly; lanes 4..7 of a block's first slot the SAME planes in front of it (:747-750).
+		const U32 after = r - 1u, before = r - 4u;
+		const Pred follows = (r >= U32(1u)) & (r < U32(4u)) & (P.k + r < U32(T)) & (((P.act >> (P.k + 1u)) & ((U32(1u) << r) - 1u)) == U32(0u));
+		const Pred leads = (r >= U32(4u)) & (r < U32(8u)) & (before < P.k) & ((P.act & ((U32(1u) << P.k) - 1u)) == U32(0u));
+		const U32 plane = sel(follows, P.k + r, before);
+		const U32 byte = (P.first >> (plane << 3)) & 0xFFu;
+		const U32 where = sel(follows, pbase + R.size + after, bbase + U32(hs) + before);
+		const Pred nib = r == U32(0u);
+		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type, byte), P.valid & (nib | follows | leads));
+	}
+	for (uint32_t i = 0; i < B.nblk; ++i) // a block without a slot: its SAME bytes (the type nibbles are all 0)
+		if (B.act[i] == 0) {
+			const U32 byte = (U32(B.first[i]) >> (lane << 3)) & 0xFFu;
+			put_small(out, (U32((i ? base1 : base0) + hs) + lane) * 8u, byte, lane < U32(T));
+		}
+	if (B.nslots == 0) {
+		wave_sync();
+		return;
+	}
+	WV_MARK("emit_rowlanes");
+	const U32 hdr = R.hdr;
+	const Pred israw = P.valid & (R.type == U32(PLANE_RAW));
+	const Pred normal = P.valid & !israw;
+	put_small(out, pbase * 8u + r * 4u, hdr, normal); // (:768-779, 758-762)
+	put_small(out, (pbase + R.minpos) * 8u, R.minb ^ 0x80u, normal & R.emitmin);
+	{
+		// mins rle mask (:765): bit r = min equals previous min
+		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
+		if (any(isnrle)) {
+			const uint64_t eqb = ballot(R.eq);
+			const U32 m16 = row_select4((uint32_t)eqb & 0xFFFFu, (uint32_t)(eqb >> 16) & 0xFFFFu, (uint32_t)(eqb >> 32) & 0xFFFFu, (uint32_t)(eqb >> 48));
+			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)));
+		}
+	}
+	WV_MARK("emit_plane");
+	const Pred is15 = hdr == U32(15u), isr = (hdr & 14u) == U32(6u);
+	const U32 bits = hdr & 7u;
+	const Pred rawrow = israw | (normal & is15);
+	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
+	const Pred rle = normal & isr;
+	const U32 rbase = pbase + sel(israw, r * 16u, R.poff);
+	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each; value - minimum on biased bytes
+	const Pred usedelta = hdr >= U32(8u);
+	const U32 mins = splat_byte0(R.minb);
+	U32 pk[4];
+	for (int k = 0; k < 4; ++k)
+		pk[k] = pack4v(sel(usedelta, R.sd[k], R.sb[k]) - mins, bits);
+	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
+	const Pred anyw = rawrow | packed;
+	const U32 own = lane * 4u; // where lanes without a row payload OR their zeros
+	const U32 s0lo = sel(rawrow, R.sb[0] ^ H, sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
+	const U32 s0hi = sel(rawrow, R.sb[1] ^ H, sel(packed, pk[1] >> ish4, U32(0u)));
+	const U32 s1lo = sel(rawrow, R.sb[2] ^ H, sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
+	const U32 s1hi = sel(rawrow, R.sb[3] ^ H, sel(packed, pk[3] >> ish4, U32(0u)));
+	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
+	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
+	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
+	if (any(rle)) {
+		const Pred is7 = hdr == U32(7u);
+		U32 f16(0u), lp = rbase + 2u;
+		for (int k = 0; k < 4; ++k) {
+			// byte == previous byte (:268-275) / delta == previous delta (:248-255)
+			const U32 bp = k ? prev_bytes(R.sb[k], R.sb[k - 1]) : prev_bytes(R.sb[0], row_shr(R.sb[3], 1, 0x80808080u));
+			const U32 dp = k ? prev_bytes(R.sd[k], R.sd[k - 1]) : ((R.sd[0] << 8) | 0x80u);
+			const U32 z = bytes_zero_mask(sel(is7, R.sb[k] ^ bp, R.sd[k] ^ dp));
+			const U32 f = zero_mask_to_bits(z);
+			f16 = f16 | (f << U32(4u * (uint32_t)k));
+			const U32 nlit = U32(4u) - popc(f);
+			put_bits(out, lp * 8u, compact_unflagged(sel(is7, R.sb[k], R.sd[k]) ^ H, f), rle & (nlit != U32(0u)));
+			lp = lp + nlit;
+		}
+		put_bits(out, rbase * 8u, f16, rle);
+	}
+	WV_MARK("emit_end");
+	wave_sync();
+}
+
+} // namespace codec

@@ -6,7 +6,7 @@
 // Reference behaviour restated here: block_compress / block_decompress outer loops
 // (stenos/internal/block_compress.h:1152-1298, 1817-1878) and block_compress_partial (:947-1020).
 #pragma once
-#include "block_codec.h"
+#include "slot_codec.h"
 
 namespace codec {
 
@@ -159,126 +159,88 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 	rs.base = stage;
 	rs.pos = 0;
 	if (slots && (T == 2 || T == 4)) {
-		// Planes in slots (block_codec.h, analyse_slots): a block whose non-constant planes leave two slots free is
-		// analysed together with its successor when that one fits into the rest.
-		const uint32_t bs = 256 * T;
+		// Planes in slots (slot_codec.h): the non-constant planes of a block, and of its successor when they fit into
+		// the four slots together, are analysed and written by row lanes in one pass.
+		const uint32_t bs = 256 * T, hs = header_bytes(T);
 		uint32_t i = 0;
 		while (i < nblocks) {
 			const uint8_t* a = src + (uint64_t)i * bs;
 			const uint8_t* b = a + bs;
 			WV_MARK("load_block");
-			// both blocks are requested at once, straight into registers; when the second one is not paired after all,
-			// its load has at least brought it closer for the next round
-			const bool fast = (((uintptr_t)a) & 15u) == 0;
-			const bool has_b = fast && i + 1 < nblocks;
-			PlaneRegs ra;
-			RawBlock eb;
-			SameScan sa;
-			uint32_t keys0 = 0, keys1 = 0; // distinct hash keys at the head of each block (first rejection test of the mini-LZ)
-			if (fast) {
+			uint32_t nblk = 1;
+			uint32_t lzq = 0; // blocks of the batch that try the mini-LZ (block_compress.h:1210-1221)
+			if ((((uintptr_t)a) & 15u) == 0) {
+				// both blocks are requested at once, straight into registers; when the second one is not paired after all,
+				// its load has at least brought it closer for the next round
+				const bool has_b = i + 1 < nblocks;
 				const RawBlock ea = load_raw_block(a, T);
+				RawBlock eb;
 				if (has_b)
 					eb = load_raw_block(b, T);
 				WV_MARK("block_begin");
-				ra = plane_regs_of(ea, T);
-				sa = T == 4 ? scan_same_raw(ea, T) : scan_same(ra, T); // two planes: one test each is the shorter way
-				if (T == 4 && sa.nact >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
-					keys0 = lz_distinct_keys_regs(lds, L, ea.e);
-			}
-			else {
-				load_block(lds, L.in, a, bs);
-				wave_sync();
-				if (T == 4)
-					keys0 = lz_distinct_keys(lds, L, T);
-				ra = load_plane_regs(lds, L.in, T, 0);
-				sa = scan_same(ra, T);
-			}
-			write_slots(lds, L, ra, T, sa.act, 0);
-			SameScan sb = sa;
-			bool pair = false;
-			if (has_b && sa.nact <= 2) {
-				PlaneRegs rb;
-				if (T == 4)
-					sb = scan_same_raw(eb, T);
-				else {
-					rb = plane_regs_of(eb, T);
-					sb = scan_same(rb, T);
+				SlotBatch B;
+				uint32_t keys0 = 0, keys1 = 0; // distinct hash keys at the head of each block (first rejection test of the mini-LZ)
+				{
+					const SameScan sa = scan_same_fast(ea, T);
+					B.act[0] = sa.act;
+					B.first[0] = sa.first;
+					B.nact0 = B.nslots = sa.nact;
+					B.act[1] = B.first[1] = 0;
 				}
-				if (sa.nact + sb.nact <= 4) {
-					if (T == 4)
-						rb = plane_regs_of(eb, T);
-					write_slots(lds, L, rb, T, sb.act, sa.nact);
-					pair = true;
-					if (T == 4 && sb.nact >= 2)
-						keys1 = lz_distinct_keys_regs(lds, L, eb.e);
-				}
-			}
-			const uint32_t nslots = sa.nact + (pair ? sb.nact : 0u);
-			wave_sync();
-			if (nslots)
-				analyse_slots(lds, L, nslots);
-			const uint32_t nblk = pair ? 2u : 1u, hs = header_bytes(T);
-			const uint32_t act1 = pair ? sb.act : 0u;
-			BatchPlan P = plan_batch(lds, L, T, sa.act, act1, nblk);
-			const uint32_t full0 = P.full[0], full1 = P.full[1];
-			bool replan = false; // an LZ attempt ran in between: the plan is rebuilt rather than kept in registers across it
-			const uint32_t size0 = hs + full0, size1 = pair ? hs + full1 : 0u;
-			uint32_t pending = pair ? 3u : 1u; // blocks whose planes still have to be written
-			// Blocks that try the mini-LZ (block_compress.h:1210-1221): those that pass its first rejection test (most do
-			// not; the key counts were taken while the blocks were in registers).  Its table is the image, so the second
-			// block's attempt has to wait until the first block is out; otherwise both blocks are written in one pass.
-			uint32_t lzq = 0;
-			if (T == 4) {
-				if (full0 * 3 > bs && lz_precheck_passes(T, keys0, full0))
-					lzq |= 1u;
-				if (pair && full1 * 3 > bs && lz_precheck_passes(T, keys1, full1))
-					lzq |= 2u;
-			}
-			bool dirty = false; // an attempt has overwritten the slot images (they share its scratch)
-			for (;;) {
-				const uint32_t blk = (lzq & 1u) ? 0u : 1u;
-				if (lzq && !(blk == 1u && (pending & 1u))) {
-					lzq &= ~(1u << blk);
-					load_block(lds, L.in, blk ? b : a, bs); // only the mini-LZ reads L.in
-					wave_sync();
-					replan = true;
-					const uint32_t n = lz_try(lds, L, T, blk ? full1 : full0, rs.pos & 15u, &dirty);
-					if (n) {
-						stream_append(rs, lds, L.out, n + 1);
-						pending &= ~(1u << blk);
+				if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
+					keys0 = lz_distinct_keys_fast(lds, L, ea.e);
+				write_slots_fast(lds, L, ea, T, B.act[0], 0);
+				if (has_b && B.nact0 <= 2) {
+					const SameScan sb = scan_same_fast(eb, T);
+					if (B.nact0 + sb.nact <= 4) {
+						B.act[1] = sb.act;
+						B.first[1] = sb.first;
+						B.nslots = B.nact0 + sb.nact;
+						nblk = 2;
+						if (T == 4 && sb.nact >= 2)
+							keys1 = lz_distinct_keys_fast(lds, L, eb.e);
+						write_slots_fast(lds, L, eb, T, sb.act, B.nact0);
 					}
+				}
+				B.nblk = nblk;
+				wave_sync();
+				SlotRows R;
+				if (B.nslots)
+					slot_rows_analyse(lds, L, R);
+				else { // only constant planes: nothing to measure
+					for (int k = 0; k < 4; ++k)
+						R.sb[k] = R.sd[k] = U32(0u);
+					R.hdr = R.minb = R.poff = R.minpos = R.type = R.size = U32(0u);
+					R.emitmin = R.eq = pred_all(false);
+				}
+				WV_MARK("plane_offsets");
+				const SlotPlace P = slot_rows_place(R, B, T);
+				if (T == 4) { // those that pass the first rejection test (most do not)
+					if (B.full[0] * 3 > bs && lz_precheck_passes(T, keys0, B.full[0]))
+						lzq |= 1u;
+					if (nblk > 1 && B.full[1] * 3 > bs && lz_precheck_passes(T, keys1, B.full[1]))
+						lzq |= 2u;
+				}
+				if (!lzq) {
+					const uint32_t base = rs.pos & 15u, size0 = hs + B.full[0], size1 = nblk > 1 ? hs + B.full[1] : 0u;
+					WV_MARK("image_reset");
+					image_reset(lds, L, base, size0 + size1);
+					slot_rows_emit(lds, L, T, R, P, B, base, base + size0);
+					WV_MARK("stream_append");
+					stream_append(rs, lds, L.out, size0 + size1);
+					WV_MARK("block_end");
+					i += nblk;
 					continue;
 				}
-				if (!pending)
-					break;
-				// write planes: both blocks in one pass, back to back in the image, when nothing stands in between
-				uint32_t mask = (pending & 1u) ? 1u : 2u;
-				if (pending == 3u && !lzq && (rs.pos & 15u) + size0 + size1 + 32u <= out_capacity(T))
-					mask = 3u;
-				if (dirty) { // rare: the planes go back into their slots
-					for (uint32_t q = 0; q < nblk; ++q) {
-						load_block(lds, L.in, q ? b : a, bs);
-						wave_sync();
-						write_slots(lds, L, load_plane_regs(lds, L.in, T, 0), T, q ? sb.act : sa.act, q ? sa.nact : 0u);
-						wave_sync();
-					}
-					dirty = false;
-				}
-				const uint32_t base = rs.pos & 15u;
-				const uint32_t bytes = ((mask & 1u) ? size0 : 0u) + ((mask & 2u) ? size1 : 0u);
-				if (replan || T == 4) { // int32: rebuilding it is cheaper than the registers it would hold meanwhile
-					P = plan_batch(lds, L, T, sa.act, act1, nblk);
-					replan = false;
-				}
-				WV_MARK("image_reset");
-				image_reset(lds, L, base, bytes);
-				emit_batch(lds, L, T, P, sa.first, sb.first, mask, base, (mask & 1u) ? base + size0 : base, sa.nact, nslots);
-				WV_MARK("stream_append");
-				stream_append(rs, lds, L.out, bytes);
-				pending &= ~mask;
 			}
-			WV_MARK("block_end");
-			i += pair ? 2u : 1u;
+			// a source that is not 16-byte aligned, or a mini-LZ attempt: the general block encoder, one block at a time
+			for (uint32_t q = 0; q < nblk; ++q) {
+				load_block(lds, L.in, q ? b : a, bs);
+				wave_sync();
+				const BlockInfo r = encode_full_block(lds, L, T, true, rs.pos & 15u);
+				stream_append(rs, lds, L.out, r.size);
+			}
+			i += nblk;
 		}
 		stream_flush(rs, lds, L.out);
 		return rs.pos;

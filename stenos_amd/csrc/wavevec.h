@@ -164,6 +164,12 @@ WV_FN U32 mulhi(const U32& a, const U32& b)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(((uint64_t)a.l[i] * b.l[i]) >> 32);
 	return r;
 }
+WV_FN U32 mul24(const U32& a, const U32& b)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (a.l[i] & 0xFFFFFFu) * (b.l[i] & 0xFFFFFFu);
+	return r;
+}
 // v_perm_b32: result byte i = byte (sel byte i) of the 8 bytes {hi:lo}; selector 0x0c gives 0
 WV_FN U32 perm_bytes(const U32& hi, const U32& lo, uint32_t selw)
 {
@@ -474,9 +480,10 @@ WV_FN U32 pk_min_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_el
 WV_FN U32 pk_max_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_elementwise_max(__builtin_bit_cast(wv_us2, a), __builtin_bit_cast(wv_us2, b))); }
 WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
 WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
+WV_FN U32 mul24(U32 a, U32 b) { return __umul24(a, b); } // low 24 bits of both operands, full rate
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN U32 perm_bytes_v(U32 hi, U32 lo, U32 selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
-WV_FN uint64_t ballot(Pred p) { return __ballot(p); }
+WV_FN uint64_t ballot(Pred p) { return __builtin_amdgcn_ballot_w64(p); }
 WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }
 // 1 when the lane mask is not empty, else 0 -- as an integer in a scalar register (a C++ bool would be kept as a
 // lane mask and turned into a number through vector registers)
@@ -540,7 +547,12 @@ WV_FN U32 row_shr(U32 a, uint32_t n, uint32_t fill)
 	}
 	if (__builtin_constant_p(fill) && fill == 0)
 		return v; // lanes without a source already read 0
-	return (lane_id() & 15u) >= n ? v : fill;
+	switch (n) { // lanes without a source keep the old value of the destination: the fill
+		case 1: return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)a, 0x111, 0xf, 0xf, false);
+		case 2: return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)a, 0x112, 0xf, 0xf, false);
+		case 4: return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)a, 0x114, 0xf, 0xf, false);
+		default: return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)a, 0x118, 0xf, 0xf, false);
+	}
 }
 // lanes 16k .. 16k+15 receive a_k (four uniform values): four moves under narrowing execution masks, no compare
 WV_FN U32 row_select4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
@@ -676,6 +688,19 @@ WV_FN void lds_st128(Lds m, U32 a, const U128& v, Pred p)
 namespace wv {
 
 WV_FN bool any(const Pred& p) { return ballot(p) != 0; }
+// Run f(p) for the first n lanes only: on the device one divergent region (p is all-true inside it), on the host a predicate.
+template <class F>
+WV_FN void lanes_below(uint32_t n, F f)
+{
+#ifdef WV_HOST_EMULATION
+	f(lane_id() < U32(n));
+#else
+	if (lane_id_plain() < n)
+		f(true);
+#endif
+}
+// byte 0 of x in all four bytes (one v_perm_b32)
+WV_FN U32 splat_byte0(const U32& x) { return perm_bytes(x, x, 0u); }
 
 // unaligned little-endian 32-bit read from LDS (two aligned reads + funnel)
 WV_FN U32 lds_ld32_unaligned(Lds m, const U32& a)
@@ -703,7 +728,7 @@ WV_FN void lds_put_bits(Lds m, const U32& bitpos, const U32& value, const Pred& 
 WV_FN void lds_put_bytes8(Lds m, const U32& pos, const U32& lo, const U32& hi)
 {
 	const U32 a = pos & ~3u;
-	const U32 selw = U32(0x07060504u) - (pos & 3u) * 0x01010101u; // bytes 4-k .. 7-k of the pair {upper, lower}
+	const U32 selw = U32(0x07060504u) - splat_byte0(pos & 3u); // bytes 4-k .. 7-k of the pair {upper, lower}
 	const U32 zero(0u);
 	lds_or32_all(m, a, perm_bytes_v(lo, zero, selw));
 	lds_or32_all(m, a + 4u, perm_bytes_v(hi, lo, selw));

@@ -198,3 +198,26 @@ def test_decoder_lds_covers_the_reach_of_an_unchecked_block(emul):
         assert total >= wcap + reach, T          # a block starting at the window's last byte stays inside
         assert total >= img + 256 * T, T         # the decoded block
         assert total <= 64 * 1024, T             # one workgroup's limit
+
+
+@pytest.mark.parametrize("T", [2, 4])
+def test_slot_rows_encoder_on_plane_mixtures(oracle, emul, T):
+    """The row-lane encoder of the fused path (slot_codec.h) on inputs whose blocks differ in which planes are constant,
+    run-length coded, delta coded, raw or LZ coded, so that batches of one and two blocks with every slot assignment
+    occur: frames equal the oracle's."""
+    from _libs import oracle_compress
+
+    emul.emul_set_fused(1)
+    emul.emul_set_slots(1)
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    per = 131072 // (256 * T) * 256
+    for kind in KINDS + (["rand12"] if T == 4 else []):
+        for seed in (1, 2, 3):
+            data = generate(kind, T, 3 * per + 256 * seed + 77, 100 + seed)
+            cap = oracle.so_bound(data.nbytes) + 5000
+            r1, f1 = oracle_compress(oracle, data, T, 1, cap)
+            out = np.zeros(cap, dtype=np.uint8)
+            r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
+            assert emul.emul_last_fused() == 3
+            assert r2 == r1 and np.array_equal(out[:r2], f1), (kind, seed)
