@@ -34,18 +34,17 @@ struct Layout {
 	uint32_t aux;     // 64 entries of 8 bytes: row statistics of the current plane group (dead once the planes are analysed)
 	uint32_t lz;      // mini-LZ chain count*4 + cur count*4, on top of aux; its 256-entry table uses the not yet written image
 	uint32_t skip;    // mini-LZ: one bit per group that was left raw (32 bytes)
+	uint32_t tab;     // 1 KiB for the tables of the mini-LZ (hash table, counters and bitmaps of its rejection tests): the image, which is
+	                  // only written once they are dead; in a unit image (below) the part behind what earlier blocks have written
+	uint32_t inplace; // unit image (make_unit_layout): blocks are appended where their predecessor ended, see image_reset
 	uint32_t total;
-	uint32_t dbg;     // diagnostics only (STENOS_DEBUG_PHASES): 1 = no LZ attempt, 2 = no emission, 4 = no analysis
 };
 
 WV_HD uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
-// A plane slot holds the 256 bytes of one plane in plane order (analyse_slots).  Stride 256 + 64: the 16-byte reads of
-// the lanes (row r, slot q) for r = 4k..4k+3, q = 0..3 fall on sixteen different groups of four banks.
-constexpr uint32_t SLOT_STRIDE = 320;
 WV_HD uint32_t lz_width(uint32_t T) { return (T % 8 == 0) ? 8u : 4u; } // lz_compress.h:285-290 for T%4==0
 WV_HD uint32_t header_bytes(uint32_t T) { return (T + 1) >> 1; }
 // a partial block can take 1 + T/2 + T*(8 + 15*17) + (16*T - 1) bytes, more than a full one
-// bytesoftype 2: two full blocks of a pair are written into the image together (emit_batch)
+// bytesoftype 2: two full blocks of a batch are written into the image together (slot_codec.h)
 WV_HD uint32_t out_capacity(uint32_t T) { return T == 2 ? 1088u : align16(280 * T + header_bytes(T) + 40); }
 
 WV_HD Layout make_layout(uint32_t T, bool with_lz)
@@ -58,25 +57,64 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	L.out = o;
 	o += out_capacity(T);
 	L.rowinfo = o;
-	o += (T < 4 ? 4 : T) * 16 * 8; // at least the four plane slots of analyse_slots
+	o += (T < 4 ? 4 : T) * 16 * 8;
 
 	L.plinfo = o;
-	o += align16(T * 4) + (T <= 4 ? 16 : 0); // bytesoftype 2 and 4: + the slot table of emit_batch
+	o += align16(T * 4);
 	L.skip = o;
 	o += 32;
 	L.aux = o;
 	L.lz = o;
 	uint32_t scratch = 64 * 8;
 	if (T == 2 || T == 4)
-		scratch += 4 * SLOT_STRIDE; // the plane slots of analyse_slots, behind the row statistics
+		scratch = 4 * 256; // the four plane slots of slot_codec.h
 	if (with_lz && T % 4 == 0) {
 		const uint32_t count = 256 * T / lz_width(T);
 		scratch = count * 8 > scratch ? count * 8 : scratch;
 	}
 	o += scratch;
 	L.total = align16(o);
-	L.dbg = 0;
+	L.tab = L.out;
+	L.inplace = 0;
 	return L;
+}
+
+// Unit images (bytesoftype 2 and 4, the streaming encoder of kernels.hip): a wavefront encodes UNIT_BYTES of input, 2 KiB,
+// into one image, block after block, and stores the image once its place in the frame is known -- while it already
+// fills the second image with the next unit (unit_image()).  Block k+1 is encoded with a layout whose image starts at
+// the 16-byte group in which block k ended (image_at); the plane slots of slot_codec.h lie in the part of the image the
+// batch is about to be written to (they are dead by then), the mini-LZ tables 1040 bytes into the image, behind anything
+// the earlier blocks of the unit can have written when a block asks for them.
+constexpr uint32_t UNIT_BYTES = 2048;
+WV_HD uint32_t unit_blocks(uint32_t T) { return UNIT_BYTES / (256 * T); }
+WV_HD uint32_t unit_image_bytes(uint32_t T) { return align16(unit_blocks(T) * (256 * T + header_bytes(T) + 1)) + 48; } // + what emission writes past the end
+WV_HD Layout make_unit_layout(uint32_t T)
+{
+	Layout L = make_layout(T, true);
+	const uint32_t grow = 2 * unit_image_bytes(T) - out_capacity(T);
+	L.rowinfo += grow;
+	L.plinfo += grow;
+	L.skip += grow;
+	L.aux += grow;
+	L.lz += grow;
+	L.total += grow;
+	L.tab = L.out + 1040;
+	L.inplace = 1;
+	return L;
+}
+// the layout for unit image k (0 or 1)
+WV_HD Layout unit_image(const Layout& L, uint32_t T, uint32_t k)
+{
+	Layout M = L;
+	M.out = L.out + k * unit_image_bytes(T);
+	M.tab = M.out + 1040;
+	return M;
+}
+WV_HD Layout image_at(const Layout& L, uint32_t pos)
+{
+	Layout M = L;
+	M.out = L.out + (pos & ~15u);
+	return M;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,75 +468,6 @@ struct SameScan {
 	uint32_t nact;  // number of such planes
 	uint32_t first; // first byte of planes 0..3, packed (the byte of a SAME plane)
 };
-WV_FN SameScan scan_same(const PlaneRegs& regs, uint32_t T)
-{
-	SameScan s;
-	s.act = 0;
-	s.nact = 0;
-	s.first = 0;
-	for (uint32_t k = 0; k < T && k < 4; ++k) {
-		const uint32_t f = readlane(regs.w[k], 0) & 0xFFu;
-		s.first |= f << (8 * k);
-		// (block_compress.h:396, 406, 415-418)
-		const uint32_t nz = mask_nonzero(ballot(regs.w[k] != U32(f * 0x01010101u)));
-		s.act |= nz << k;
-		s.nact += nz;
-	}
-	return s;
-}
-// The same from the elements themselves (bytesoftype 2 or 4): byte k of the OR over all elements of (element ^ first
-// element) is non-zero exactly when plane k is not constant.  Fewer scalar instructions than four separate tests.
-WV_FN SameScan scan_same_raw(const RawBlock& b, uint32_t T)
-{
-	SameScan s;
-	U32 x;
-	if (T == 2) {
-		const uint32_t e0 = readlane(b.e.x, 0) & 0xFFFFu;
-		const U32 e(e0 * 0x00010001u);
-		x = (b.e.x ^ e) | (b.e.y ^ e);
-		x = (x | (x >> 16)) & 0xFFFFu;
-		s.first = e0;
-	}
-	else {
-		const uint32_t e0 = readlane(b.e.x, 0);
-		const U32 e(e0);
-		x = ((b.e.x ^ e) | (b.e.y ^ e)) | ((b.e.z ^ e) | (b.e.w ^ e));
-		s.first = e0;
-	}
-	const uint32_t any = wave_or(x);
-	// lanes 0..3 look at one byte each
-	const U32 k = lane_id() & 3u;
-	s.act = (uint32_t)ballot(((U32(any) >> (k << 3)) & 0xFFu) != U32(0u)) & 0xFu;
-	s.nact = (uint32_t)__builtin_popcount(s.act);
-	return s;
-}
-WV_HD uint32_t slot_image(const Layout& L, uint32_t s) { return L.aux + 64 * 8 + s * SLOT_STRIDE; }
-// the non-constant planes of a block -> slots slot, slot + 1, ...
-WV_FN void write_slots(Lds lds, const Layout& L, const PlaneRegs& regs, uint32_t T, uint32_t act, uint32_t slot)
-{
-	const U32 lane = lane_id();
-	for (uint32_t k = 0; k < T && k < 4; ++k)
-		if ((act >> k) & 1u) {
-			lds_st32(lds, U32(slot_image(L, slot)) + lane * 4u, regs.w[k], pred_all(true));
-			++slot;
-		}
-}
-// Analyse slots [0, nslots) as full-block planes: row headers -> L.rowinfo entry slot*16 + row, L.plinfo[slot] = type | size << 8.
-WV_FN void analyse_slots(Lds lds, const Layout& L, uint32_t nslots)
-{
-	const U32 lane = lane_id();
-	WV_MARK("analyse_stage1");
-	U128 v = lds_ld128(lds, U32(slot_image(L, 0)) + (lane & 3u) * SLOT_STRIDE + (lane >> 2) * 16u);
-	U32 b[4];
-	b[0] = v.x;
-	b[1] = v.y;
-	b[2] = v.z;
-	b[3] = v.w;
-	row_stats_store(lds, L, b); // slots past nslots hold stale bytes: their results are ignored
-	wave_sync();
-	analyse_stage2(lds, L, 0, nslots, true, 16, nullptr);
-}
-
 // What the frame assembly needs to know about an encoded block to reproduce the reference's
 // capacity rules (block_compress.h:1214, 1225, 1241; block_compress_partial :984, 994, 1013):
 //   info = full | need << 15 | eligible << 30 | lz_ok << 31
@@ -665,142 +634,6 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 	wave_sync();
 }
 
-// ---- blocks analysed in slots: plane table and emission on lanes --------------------------------------------
-// A batch is one block or two consecutive ones whose non-constant planes fill slots 0 .. nslots-1 (block 0 first).
-// Lane 4*blk + k of every group of eight lanes stands for plane k of block blk.
-struct BatchPlan {
-	U32 type, off, slot; // plane type, offset of the plane in its block's encoding, slot of a non-constant plane
-	Pred inblock, active;
-	uint32_t full[2];    // sum of the plane sizes of each block (block_compress.h:1189-1207)
-};
-WV_FN BatchPlan plan_batch(Lds lds, const Layout& L, uint32_t T, uint32_t act0, uint32_t act1, uint32_t nblk)
-{
-	BatchPlan P;
-	const U32 lane = lane_id();
-	const U32 k = lane & 3u;
-	const Pred second = ((lane >> 2) & 1u) == U32(1u);
-	const U32 actv = sel(second, U32(act1), U32(act0));
-	P.inblock = (k < U32(T)) & (sel(second, U32(1u), U32(0u)) < U32(nblk));
-	P.active = P.inblock & (((actv >> k) & 1u) == U32(1u));
-	P.slot = popc(actv & ((U32(1u) << k) - 1u)) + sel(second, popc(U32(act0)), U32(0u)); // slots follow block and plane order
-	U32 pinfo = lds_ld32(lds, U32(L.plinfo) + sel(P.active, P.slot, U32(0u)) * 4u);
-	pinfo = sel(P.active, pinfo, sel(P.inblock, U32(PLANE_SAME | (1u << 8)), U32(0u)));
-	P.type = pinfo & 0xFFu;
-	const U32 size = pinfo >> 8;
-	U32 incl = size + sel(k >= U32(1u), row_shr(size, 1, 0), U32(0u)); // prefix sums inside the quad
-	incl = incl + sel(k >= U32(2u), row_shr(incl, 2, 0), U32(0u));
-	P.off = U32(header_bytes(T)) + incl - size;
-	P.full[0] = readlane(incl, 3);
-	P.full[1] = readlane(incl, 7);
-	return P;
-}
-
-// four values of at most `bits` bits, one per byte of x -> 4*bits bits
-WV_FN U32 pack4(const U32& x, const U32& bits)
-{
-	U32 t = (x & 0x00FF00FFu) | (((x >> 8) & 0x00FF00FFu) << bits);
-	return (t & 0xFFFFu) | ((t >> 16) << (bits + bits));
-}
-
-// Write the blocks of a batch named by `mask` (bit blk) into the zeroed image, block blk starting at byte base[blk]:
-// type nibbles and SAME bytes by the plane lanes, then lane 16s + r writes row r of slot s -- row header, minimum and
-// payload in one pass over all slots (block_compress.h:739-806, 1246-1257).  nslots0: slots of block 0, nslots: of both.
-WV_FN void emit_batch(Lds lds, const Layout& L, uint32_t T, const BatchPlan& P, uint32_t first0, uint32_t first1, uint32_t mask, uint32_t base0,
-		      uint32_t base1, uint32_t nslots0, uint32_t nslots)
-{
-	const U32 lane = lane_id();
-	Lds out = lds + L.out;
-	WV_MARK("emit_nibbles");
-	{
-		const U32 k = lane & 3u;
-		const Pred second = ((lane >> 2) & 1u) == U32(1u);
-		const Pred pending = ((U32(mask) >> sel(second, U32(1u), U32(0u))) & 1u) == U32(1u);
-		const Pred mine = P.inblock & pending & (lane < U32(8u));
-		const U32 bbase = sel(second, U32(base1), U32(base0));
-		const U32 nib = quad_add(sel(P.inblock, P.type << (k << 2), U32(0u)));
-		lds_put_bits(out, bbase * 8u, nib, mine & (k == U32(0u)));
-		const U32 byte = (sel(second, U32(first1), U32(first0)) >> (k << 3)) & 0xFFu; // (:747-750)
-		lds_put_small(out, (bbase + P.off) * 8u, byte, mine & (P.type == U32(PLANE_SAME)));
-		lds_st32(lds, U32(L.plinfo + 16u) + sel(P.active, P.slot, U32(0u)) * 4u, P.type | ((bbase + P.off) << 8), mine & P.active);
-		wave_sync();
-	}
-	if (((mask & 1u) ? nslots0 : 0u) + ((mask & 2u) ? nslots - nslots0 : 0u) == 0) // only constant planes: nothing for the slot lanes
-		return;
-	WV_MARK("emit_rowlanes");
-	const U32 s = lane >> 4, r = lane & 15u;
-	const U32 sinfo = lds_ld32(lds, U32(L.plinfo + 16u) + s * 4u);
-	const Pred svalid = sel(s < U32(nslots0), U32(mask & 1u), sel(s < U32(nslots), U32((mask >> 1) & 1u), U32(0u))) == U32(1u);
-	const U32 type = sinfo & 0xFFu, pbase = sinfo >> 8;
-	const Pred normal = svalid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
-	const Pred israw = svalid & (type == U32(PLANE_RAW));
-	U32 lo, hi;
-	lds_ld64(lds, U32(L.rowinfo) + lane * 8u, lo, hi);
-	const U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
-	lds_put_small(out, pbase * 8u + r * 4u, hdr, normal); // (:768-779, 758-762)
-	lds_put_small(out, (pbase + (hi & 0xFFFu)) * 8u, minv, normal & (((hi >> 12) & 1u) == U32(1u)));
-	{
-		// mins rle mask (:765): bit r = min equals previous min
-		const uint64_t eqb = ballot(((hi >> 13) & 1u) == U32(1u));
-		const U32 half = sel(s < U32(2u), U32((uint32_t)eqb), U32((uint32_t)(eqb >> 32)));
-		const U32 m16 = (half >> ((s & 1u) << 4)) & 0xFFFFu;
-		lds_put_bits(out, (pbase + 8u) * 8u, m16, svalid & (type == U32(PLANE_NORMAL_RLE)) & (r == U32(0u)));
-	}
-	WV_MARK("emit_plane");
-	// the row's 16 bytes and their deltas against the previous byte in plane order, 0 before the plane (:399-401)
-	U128 bv = lds_ld128(lds, U32(slot_image(L, 0)) + s * SLOT_STRIDE + r * 16u);
-	U32 b[4], d[4];
-	b[0] = bv.x;
-	b[1] = bv.y;
-	b[2] = bv.z;
-	b[3] = bv.w;
-	const Pred is15 = hdr == U32(15u), is7 = hdr == U32(7u), is6 = hdr == U32(6u);
-	const U32 bits = hdr & 7u;
-	const Pred rawrow = israw | (normal & is15);
-	const Pred packed = normal & !is15 & !is7 & !is6 & (bits != U32(0u));
-	const Pred rle = normal & (is7 | is6);
-	const bool any_rle = any(rle);
-	if (any_rle || any(packed & (hdr >= U32(8u)))) { // no delta-coded or run-length row: nobody needs the deltas
-		const U32 prev = row_shr(b[3] >> 24, 1, 0);
-		d[0] = bytes_sub(b[0], (b[0] << 8) | prev);
-		for (int k = 1; k < 4; ++k)
-			d[k] = bytes_sub(b[k], (b[k] << 8) | (b[k - 1] >> 24));
-	}
-	else
-		d[0] = d[1] = d[2] = d[3] = U32(0u);
-	const U32 rbase = sel(israw, pbase + r * 16u, pbase + (lo >> 16));
-	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each
-	const Pred usedelta = hdr >= U32(8u);
-	const U32 mins = bytes_splat(minv);
-	U32 pk[4];
-	for (int k = 0; k < 4; ++k)
-		pk[k] = pack4(bytes_sub(sel(usedelta, d[k], b[k]), mins), bits);
-	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
-	const Pred anyw = rawrow | packed;
-	const U32 own = lane * 4u; // where lanes without a row payload OR their zeros
-	U32 s0lo = sel(rawrow, b[0], sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
-	U32 s0hi = sel(rawrow, b[1], sel(packed, pk[1] >> ish4, U32(0u)));
-	U32 s1lo = sel(rawrow, b[2], sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
-	U32 s1hi = sel(rawrow, b[3], sel(packed, pk[3] >> ish4, U32(0u)));
-	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
-	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
-	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
-	if (any_rle) {
-		U32 f16(0u), lp = rbase + 2u;
-		for (int k = 0; k < 4; ++k) {
-			const U32 pd = k ? (d[k - 1] >> 24) : U32(0u);
-			const U32 z = bytes_zero_mask(sel(is7, d[k], d[k] ^ ((d[k] << 8) | pd))); // byte == previous byte (:268-275) / delta == previous delta (:248-255)
-			const U32 f = zero_mask_to_bits(z);
-			f16 = f16 | (f << U32(4u * (uint32_t)k));
-			const U32 nlit = U32(4u) - popc(f);
-			lds_put_bits(out, lp * 8u, compact_unflagged(sel(is7, b[k], d[k]), f), rle & (nlit != U32(0u)));
-			lp = lp + nlit;
-		}
-		lds_put_bits(out, rbase * 8u, f16, rle);
-	}
-	WV_MARK("emit_end");
-	wave_sync();
-}
-
 // zero `bytes` (multiple of 16, 16-byte aligned) of LDS at `off`
 WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
 {
@@ -815,8 +648,19 @@ WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
 // Zeroed image for an encoding of `size` bytes that starts at byte `base` (< 16) of the image.  A block that is
 // appended to a stream (superblock_codec.h, RunStream) starts behind the bytes of its predecessor that did not fill
 // a 16-byte group: they wait, padded with zeros, in the 16 bytes in front of the image and become its first group.
+// In a unit image (L.inplace) those bytes are where the predecessor wrote them and stay there.
 WV_FN void image_reset(Lds lds, const Layout& L, uint32_t base, uint32_t size)
 {
+	if (L.inplace && base) {
+		lds_zero(lds, L.out + 16u, align16(base + size));
+		const U32 lane = lane_id();
+		const Pred p = lane < U32(4u);
+		const U32 a = sel(p, lane, U32(0u)) * 4u;
+		const U32 keep = sel(a + 4u <= U32(base), U32(0xFFFFFFFFu), sel(a >= U32(base), U32(0u), (U32(1u) << ((U32(base) - a) << 3)) - 1u));
+		lds_st32(lds, U32(L.out) + a, lds_ld32(lds, U32(L.out) + a) & keep, p);
+		wave_sync();
+		return;
+	}
 	lds_zero(lds, L.out, align16(base + size) + 16u);
 	if (base) {
 		const U32 lane = lane_id();
@@ -883,7 +727,7 @@ WV_FN uint32_t lz_distinct_keys(Lds lds, const Layout& L, uint32_t T)
 {
 	const U32 lane = lane_id();
 	const uint32_t B = lz_width(T);
-	const uint32_t tab = L.out;
+	const uint32_t tab = L.tab;
 	const uint32_t nq = lz_precheck_values(T);
 	WV_MARK("lz_try");
 	U128 z;
@@ -901,27 +745,6 @@ WV_FN uint32_t lz_distinct_keys(Lds lds, const Layout& L, uint32_t T)
 	wave_sync();
 	return distinct;
 }
-// the same for a block of bytesoftype 4 that is still in registers (the lane's four elements): the first nq = 80
-// values are those of lanes 0..19
-WV_FN uint32_t lz_distinct_keys_regs(Lds lds, const Layout& L, const U128& e)
-{
-	const U32 lane = lane_id();
-	const uint32_t tab = L.out;
-	U128 z;
-	z.x = z.y = z.z = z.w = U32(0u);
-	lds_st128(lds, U32(tab) + lane * 16u, z, pred_all(true));
-	wave_sync();
-	const Pred in = lane < U32(lz_precheck_values(4) / 4);
-	uint32_t distinct = 0;
-	const U32 v[4] = { e.x, e.y, e.z, e.w };
-	for (int k = 0; k < 4; ++k) {
-		U32 key = (v[k] * 2654435761u) & 255u; // hash_val (lz_compress.h:47-56)
-		U32 old = lds_add_rtn32(lds, U32(tab) + key * 4u, U32(1u), in);
-		distinct += (uint32_t)__builtin_popcountll(ballot(in & (old == U32(0u))));
-	}
-	wave_sync();
-	return distinct;
-}
 WV_FN bool lz_precheck(Lds lds, const Layout& L, uint32_t T, uint32_t max_size) { return lz_precheck_passes(T, lz_distinct_keys(lds, L, T), max_size); }
 // *scratch_used (optional) is set once the attempt gets past its first rejection test and starts using L.lz.
 WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, uint32_t base, bool* scratch_used = nullptr)
@@ -929,7 +752,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	const U32 lane = lane_id();
 	const uint32_t B = lz_width(T);
 	const uint32_t count = 256 * T / B, nchunks = count / 64;
-	const uint32_t tab = L.out, chain = L.lz, cur = chain + count * 4; // the image is written last: its first KiB serves as the table
+	const uint32_t tab = L.tab, chain = L.lz, cur = chain + count * 4; // the image is written last: it serves as the table until then
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
 	if (!lz_precheck(lds, L, T, max_size))
 		return 0;
@@ -1148,8 +971,7 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 	const PlaneRegs regs = load_plane_regs(lds, L.in, T, 0);
 	const bool small = T <= 4; // one plane group: its table lives in scalars
 	uint32_t tab[4] = { 0u, 0u, 0u, 0u };
-	if (!(L.dbg & 4u))
-		for (uint32_t g = 0; g < T; g += 4)
+	for (uint32_t g = 0; g < T; g += 4)
 			analyse_group(lds, L, T, g, T - g < 4 ? T - g : 4, true, 16, regs, small ? tab : nullptr);
 	uint32_t need;
 	WV_MARK("plane_offsets");
@@ -1157,7 +979,7 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
 	BlockInfo r;
 	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
-	if (allow_lz && eligible && !(L.dbg & 1u)) {
+	if (allow_lz && eligible) {
 		uint32_t n = lz_try(lds, L, T, full, base);
 		if (n) {
 			r.size = n + 1;
@@ -1167,8 +989,7 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 	}
 	WV_MARK("image_reset");
 	image_reset(lds, L, base, header_bytes(T) + full); // a failed LZ attempt leaves its table there
-	if (!(L.dbg & 2u))
-		emit_planes(lds, L, T, base, 16, regs, small ? tab : nullptr);
+	emit_planes(lds, L, T, base, 16, regs, small ? tab : nullptr);
 	r.size = header_bytes(T) + full;
 	return r;
 }

@@ -192,7 +192,7 @@ struct stenos_context_s {
 	DevBuf chain;                                    // fused path: ticket counter + one chained-scan word per superblock
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
-	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) int32 plane probe, [24,32) scan carry, [64,320) override payload
+	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) unused, [24,32) scan carry, [64,320) override payload
 	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage; // host staging of the strategy layer
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
@@ -389,21 +389,40 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	// One arena serves both: the staging streams of the fused superblocks, then (the fused kernel is done by
 	// then) the 16-byte aligned slots of the remaining blocks, addressed by their absolute block number.
 	const uint64_t b_unfused = first_block(s_fused);
+	// bytesoftype 2 and 4 stream their encodings from LDS to the frame (kernels.hip, encode_stream); the other sizes
+	// stage them in the arena first (encode_superblocks)
+	const bool streaming = s_fused && stenos_k_stream_supported((uint32_t)T, f.bps);
 	if (level >= 1) {
-		const size_t stage_bytes = s_fused ? stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused) : 0;
+		const size_t stage_bytes = s_fused && !streaming ? stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused) : 0;
 		const size_t slot_bytes = (size_t)(nblocks_all - b_unfused + 1) * stride;
 		if (!ctx->slots.ensure(stage_bytes > slot_bytes ? stage_bytes : slot_bytes))
 			return STENOS_ERROR_ALLOC;
 		j.slots = ctx->slots.as<uint8_t>() - b_unfused * (uint64_t)stride;
 	}
-	if (s_fused) {
+	if (streaming) {
+		// chain: [size words of the scanner: s_fused + 2][done words: s_fused][unit words and ticket counters]
+		const size_t words64 = (s_fused + 2) + s_fused + (stenos_k_stream_words(s_fused) + 1) / 2;
+		if (!ctx->chain.ensure(words64 * 8))
+			return STENOS_ERROR_ALLOC;
+		uint64_t* size = ctx->chain.as<uint64_t>();
+		uint64_t* done = size + s_fused + 2;
+		uint32_t* agg = (uint32_t*)(done + s_fused);
+		uint32_t* tickets = agg + s_fused * 64;
+		if (stenos_k_launch_init(misc, header, size, words64, j.sb_off, s_fused + 8, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		ctx->mark(0, stream);
+		if (stenos_k_launch_encode_stream(j, s_fused, agg, done, size, tickets, d_carry, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		ctx->mark(1, stream);
+	}
+	else if (s_fused) {
 		if (!ctx->chain.ensure((s_fused + 2) * 8))
 			return STENOS_ERROR_ALLOC;
 		uint64_t* desc = ctx->chain.as<uint64_t>() + 1; // word 0: ticket counter
 		if (stenos_k_launch_init(misc, header, ctx->chain.as<uint64_t>(), s_fused + 2, j.sb_off, s_fused + 8, stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 		ctx->mark(0, stream);
-		if (stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, (uint32_t*)(misc + 20), stream) != hipSuccess)
+		if (stenos_k_launch_encode_fused(j, s_fused, ctx->slots.as<uint8_t>(), desc, ctx->chain.as<uint32_t>(), d_carry, stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 		ctx->mark(1, stream);
 	}

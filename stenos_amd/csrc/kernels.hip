@@ -29,11 +29,10 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 template <uint32_t TT>
 __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t b_begin, uint64_t b_end, uint64_t nfull, uint32_t tail_bytes, uint32_t Trt,
 						    uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ bsize,
-						    uint32_t* __restrict__ binfo, uint32_t dbg)
+						    uint32_t* __restrict__ binfo)
 {
 	const uint32_t T = TT ? TT : Trt;
-	Layout L = make_layout(T, true);
-	L.dbg = dbg; // diagnostics only, 0 in normal operation
+	const Layout L = make_layout(T, true);
 	for (uint64_t b = b_begin + blockIdx.x; b < b_end; b += gridDim.x) {
 		BlockInfo r;
 		if (b < nfull)
@@ -58,7 +57,7 @@ __global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint
 		*(uint64_t*)misc = first_off;
 		*(uint32_t*)(misc + 12) = 0u;
 		*(uint32_t*)(misc + 16) = 0xFFFFFFFFu;
-		*(uint32_t*)(misc + 20) = 0u; // probe_planes' count
+		*(uint32_t*)(misc + 20) = 0u;
 		*(uint64_t*)(misc + 24) = first_off;
 	}
 	for (uint64_t k = i; k < n1; k += step)
@@ -66,21 +65,6 @@ __global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint
 	for (uint64_t k = i; k < n2; k += step)
 		z2[k] = 0;
 }
-
-// ---- which block loop suits the data (int32) ----------------------------------------------------------------
-// The slot encoder wins when blocks have at most two non-constant planes (it analyses and writes them in pairs), the
-// plane-group loop when they have three or four (floats, noise).  PROBE_SAMPLES blocks spread over the input are
-// looked at; *busy counts those with three or four.  Two instantiations of the fused kernel are launched and the one
-// the count does not ask for returns at once: one kernel with both loops would be large enough to slow down either.
-constexpr uint32_t PROBE_SAMPLES = 64;
-__global__ __launch_bounds__(64) void probe_planes(const uint8_t* __restrict__ src, uint64_t nfull, uint32_t* __restrict__ busy)
-{
-	const uint64_t b = nfull / PROBE_SAMPLES * blockIdx.x;
-	const SameScan s = scan_same_raw(load_raw_block(src + b * 1024ull, 4), 4);
-	if (threadIdx.x == 0 && s.nact >= 3)
-		atomicAdd(busy, 1u);
-}
-__device__ inline bool probe_says_groups(const uint32_t* busy) { return *(const volatile uint32_t*)busy * 2u > PROBE_SAMPLES; }
 
 // ---- fused path -----------------------------------------------------------------------------------------
 // Frame offsets of the superblocks are produced while the encoders run.  Every workgroup publishes the bytes its
@@ -97,6 +81,10 @@ constexpr uint64_t CHAIN_FAILED = ~0ull;
 #define STENOS_FUSED_TICKETS 1
 #endif
 constexpr uint32_t FUSED_TICKETS = STENOS_FUSED_TICKETS; // superblocks per encoder workgroup
+#ifndef STENOS_FUSED_OCCUPANCY
+#define STENOS_FUSED_OCCUPANCY 8
+#endif
+constexpr uint32_t FUSED_OCCUPANCY = STENOS_FUSED_OCCUPANCY; // waves per SIMD the register allocation of the fused kernel aims at
 
 __device__ inline void chain_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint64_t chain_get(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -193,23 +181,17 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 // Workgroup 0: the scanner.  Every other workgroup: FUSED_WAVES wavefronts that take FUSED_TICKETS superblocks one
 // after the other -- encode (each wave a run of consecutive blocks into its staging stream), publish the size,
 // then store the previous superblock at its offset (pipeline.h, fused_store).
-// GROUPS (int32 only): the instantiation with the plane-group loop; it and its twin look at the probe's count (busy) and
-// the one that is not wanted returns.
-template <uint32_t TT, bool GROUPS>
-__global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
-									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry, uint32_t dbg,
-									const uint32_t* __restrict__ busy)
+template <uint32_t TT>
+__global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
+									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
 {
-	if (TT == 4 && probe_says_groups(busy) != GROUPS)
-		return;
 	if (blockIdx.x == 0) {
 		if (threadIdx.x < 64)
 			chain_scanner(j, nsb, size, carry);
 		return;
 	}
 	const uint32_t T = TT ? TT : j.T;
-	Layout L = make_layout(T, true);
-	L.dbg = dbg; // diagnostics only, 0 in normal operation
+	const Layout L = make_layout(T, true);
 	const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total); // [0] ticket, [8 + 4*parity ..] run sizes
 	uint32_t b0, b1;
@@ -229,7 +211,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJ
 #ifdef STENOS_EXP_STATS
 			const uint64_t te = __builtin_readcyclecounter();
 #endif
-			const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w, !GROUPS);
+			const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0, stage_w);
 			if ((threadIdx.x & 63u) == 0)
 				runs[w] = n;
 #ifdef STENOS_EXP_STATS
@@ -288,6 +270,187 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 8) void encode_superblocks(FrameJ
 		}
 #endif
 	}
+}
+
+// ---- streaming path (bytesoftype 2 and 4) ------------------------------------------------------------------
+// Workgroup 0: the scanner.  Every other wavefront takes units (pipeline.h) in frame order, each on its own: it encodes a
+// unit into one of its two LDS images, publishes the bytes it takes (agg[unit], non-zero) and counts itself in done[s]
+// (units published, high half; their bytes, low half).  The unit that completes the count hands the superblock's bytes
+// in the frame to the scanner (size[s]).  Once all units of its superblock are counted -- one word to poll -- a wavefront
+// reads their words, which gives it the bytes in front of its own and the superblock's total (BLOCK or COPY,
+// stenos.cpp:609-610), and with the superblock's frame offset from the scanner (sb_off[s]) the image goes straight to its
+// place.  Nothing is staged in HBM.  A wavefront stores a unit after it has encoded the next one into its other image,
+// by which time what it needs to know has normally arrived; it polls in earnest only when both images are full.
+//
+// Progress.  Tickets are drawn from `shards` counters (a single one saturates near 90 tickets per microsecond): counter
+// c hands out the units c, c + shards, c + 2 * shards, ... to the wavefronts whose number (among the encoders) is c
+// modulo shards.  A wavefront never waits while it holds a ticket whose unit it has not published: between drawing a
+// ticket and publishing the unit it only probes, once, whether its older unit can be stored.  It waits for units of its
+// own superblock (at most 63 ahead of its own) and for superblocks before it.  Take the smallest unit nobody has drawn:
+// the wavefronts of its counter all hold smaller units of that counter, the holder of the smallest of those waits only
+// for units below the undrawn one, which are all drawn and get published without waiting, so it finishes and draws
+// the next.  Hence every wait ends as long as every counter has a running wavefront, which the grid size guarantees;
+// a poll counter bounds the waits anyway and reports a stall as an error.
+constexpr uint32_t STREAM_WAVES = 4;
+constexpr uint32_t STREAM_MAX_SHARDS = 128;
+#ifndef STENOS_STREAM_OCCUPANCY
+#define STENOS_STREAM_OCCUPANCY 7
+#endif
+constexpr uint32_t AGG_READY = 0x80000000u;
+
+__device__ inline void agg_put(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t agg_get(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t uniform64(uint64_t v)
+{
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+}
+
+template <uint32_t TT>
+__global__ __launch_bounds__(64 * STREAM_WAVES, STENOS_STREAM_OCCUPANCY) void encode_stream(FrameJob j, uint64_t nsb, uint32_t* __restrict__ agg, uint64_t* __restrict__ done,
+											   uint64_t* __restrict__ size, uint32_t* __restrict__ tickets, uint64_t* __restrict__ carry,
+											   uint32_t shards)
+{
+	if (blockIdx.x == 0) {
+		if (threadIdx.x < 64)
+			chain_scanner(j, nsb, size, carry);
+		return;
+	}
+	constexpr uint32_t T = TT;
+	const Layout L = make_unit_layout(T);
+	const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63u;
+	Lds lds = g_lds + w * L.total;
+	constexpr uint32_t ups = 64; // units per superblock (pipeline.h, stream_supported)
+	const uint64_t nunits = nsb * ups;
+	const uint32_t shard = ((blockIdx.x - 1) * STREAM_WAVES + w) % shards;
+	uint32_t* const my_tickets = tickets + shard * 32u; // a cache line per counter
+
+	// the unit that is encoded and published but not stored yet
+	uint64_t pend_unit = ~0ull;
+	uint32_t pend_n = 0, pend_image = 0;
+	// What storing the pending unit takes, requested in one go: lane 0 the count of its superblock, lane 1 the superblock's
+	// frame offset; every lane the word of one unit of the superblock.
+	struct Probe {
+		uint64_t word;
+		uint32_t unit_word;
+	};
+	auto probe = [&]() -> Probe {
+		const uint64_t s = pend_unit / ups;
+		Probe p;
+		p.word = chain_get((lane == 1 ? j.sb_off : done) + s);
+		p.unit_word = agg_get(agg + s * ups + lane);
+		return p;
+	};
+	auto store_if_ready = [&](const Probe& p) -> bool {
+		const uint64_t s = pend_unit / ups;
+		const uint32_t i = (uint32_t)(pend_unit % ups);
+		const uint32_t counted = readlane((uint32_t)(p.word >> 32), 0);
+		const uint64_t off = (uint64_t)readlane((uint32_t)p.word, 1) | ((uint64_t)readlane((uint32_t)(p.word >> 32), 1) << 32);
+		// (a word that has not arrived although its unit is counted shows by its missing flag)
+		if (counted != ups || off == 0 || __builtin_amdgcn_ballot_w64(p.unit_word == 0) != 0)
+			return false;
+		const uint32_t bytes = p.unit_word & ~AGG_READY;
+		const uint32_t incl = wave_incl_scan(bytes);
+		unit_store(j, lds, unit_image(L, T, pend_image), s, i, off, readlane(incl - bytes, i), readlane(incl, 63), pend_n);
+		pend_unit = ~0ull;
+		return true;
+	};
+	// A ticket may be drawn one unit ahead (its latency then hides behind the encoding) when the units a wavefront can wait
+	// for, those below the end of its pending unit's superblock, lie below the unit drawn ahead: 2 * shards >= ups.
+	const bool ahead = shards * 2 >= ups;
+	auto draw = [&]() -> uint32_t { return lane == 0 ? atomicAdd(my_tickets, 1u) : 0u; };
+	auto unit_of = [&](uint32_t t) -> uint64_t { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(t) * shards + shard; };
+#ifdef STENOS_EXP_STATS
+	uint64_t st_enc = 0, st_pub = 0, st_poll = 0, st_store = 0, st_polls = 0, st_units = 0, st_blocked = 0, st_t0 = 0;
+#define ST_BEGIN st_t0 = __builtin_readcyclecounter()
+#define ST_END(x) x += __builtin_readcyclecounter() - st_t0
+#else
+#define ST_BEGIN
+#define ST_END(x)
+#endif
+	uint64_t unit = unit_of(draw());
+	while (unit < nunits) {
+		uint32_t t_next = 0;
+		if (ahead)
+			t_next = draw();
+		Probe p;
+		p.word = 0;
+		p.unit_word = 0;
+		if (pend_unit != ~0ull)
+			p = probe(); // answered while the unit is encoded
+		const uint32_t image = pend_unit != ~0ull ? pend_image ^ 1u : 0u;
+		ST_BEGIN;
+		const uint32_t n = encode_unit(lds, unit_image(L, T, image), T, j.src + unit * (uint64_t)UNIT_BYTES, unit_blocks(T));
+		ST_END(st_enc);
+		ST_BEGIN;
+		if (lane == 0) {
+			agg_put(agg + unit, n | AGG_READY);
+			// The unit that completes its superblock's count hands the superblock's bytes in the frame to the scanner, right
+			// here, where it waits for nothing: the chain of offsets must not run through anybody's waiting.
+			const uint64_t before = __hip_atomic_fetch_add(done + unit / ups, (1ull << 32) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((uint32_t)(before >> 32) == ups - 1) {
+				const uint32_t total = (uint32_t)before + n;
+				chain_put(size + unit / ups, 4ull + (total > j.sb_bytes ? j.sb_bytes : total));
+			}
+		}
+		ST_END(st_pub);
+#ifdef STENOS_EXP_STATS
+		++st_units;
+#endif
+		ST_BEGIN;
+		const bool stored_at_once = pend_unit == ~0ull || store_if_ready(p);
+		ST_END(st_store);
+		if (!stored_at_once) { // both images are full: poll
+#ifdef STENOS_EXP_STATS
+			++st_blocked;
+			const uint64_t tp = __builtin_readcyclecounter();
+#endif
+			uint32_t spins = 0;
+			for (;;) {
+				__builtin_amdgcn_s_sleep(4);
+#ifdef STENOS_EXP_STATS
+				++st_polls;
+#endif
+				if (store_if_ready(probe())) {
+#ifdef STENOS_EXP_STATS
+					st_poll += __builtin_readcyclecounter() - tp;
+#endif
+					break;
+				}
+				if (++spins > CHAIN_SPIN_LIMIT) {
+					if (lane == 0)
+						atomicOr(j.status, ENCODE_STATUS_CHAIN_TIMEOUT);
+					return;
+				}
+			}
+		}
+		pend_unit = unit;
+		pend_n = n;
+		pend_image = image;
+		unit = unit_of(ahead ? t_next : draw());
+	}
+	for (uint32_t spins = 0; pend_unit != ~0ull; ++spins) {
+		if (store_if_ready(probe()))
+			break;
+		if (spins > CHAIN_SPIN_LIMIT) {
+			if (lane == 0)
+				atomicOr(j.status, ENCODE_STATUS_CHAIN_TIMEOUT);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(4);
+	}
+#ifdef STENOS_EXP_STATS
+	if (lane == 0) {
+		unsigned long long* st = (unsigned long long*)(j.sb_off + nsb + 2);
+		atomicAdd(st + 0, st_enc);
+		atomicAdd(st + 1, st_pub);
+		atomicAdd(st + 2, st_poll);
+		atomicAdd(st + 3, st_store);
+		atomicAdd(st + 4, st_polls);
+		atomicAdd(st + 5, st_units);
+		atomicAdd(st + 6, st_blocked);
+	}
+#endif
 }
 
 // One wavefront per superblock.
@@ -461,7 +624,7 @@ static hipError_t launch_encode_t(const FrameJob& j, uint64_t b_begin, uint64_t 
 		grid = (uint32_t)(nblocks < resident ? nblocks : resident);
 	}
 	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, b_begin, b_end, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride,
-			   j.bsize, j.binfo, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u);
+			   j.bsize, j.binfo);
 	return hipGetLastError();
 }
 
@@ -474,44 +637,59 @@ hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1,
 	return hipGetLastError();
 }
 
-template <uint32_t TT, bool GROUPS>
-static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, const uint32_t* busy,
-				 hipStream_t stream)
+template <uint32_t TT>
+static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
 {
 	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 64;
-	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT, GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
 	const uint32_t grid = (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS) + 1; // + the scanner
-	hipLaunchKernelGGL((encode_superblocks<TT, GROUPS>), dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc,
-			   ticket, carry, getenv("STENOS_DEBUG_PHASES") ? (uint32_t)atoi(getenv("STENOS_DEBUG_PHASES")) : 0u, busy);
+	hipLaunchKernelGGL((encode_superblocks<TT>), dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc, ticket, carry);
 	return hipGetLastError();
 }
 
 // Superblocks [0, nsb) of the job, all of them bps full blocks with room for any encoding.  desc: nsb zeroed words,
 // ticket: one zeroed word, j.sb_off[0, nsb] zeroed, stage: stenos_k_fused_stage_bytes(); *carry receives the frame
-// offset behind them.  busy: a zeroed word (init_job clears it) for the int32 probe.
-hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, uint32_t* busy,
-					hipStream_t stream)
+// offset behind them.
+hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
 {
 	if (nsb == 0)
 		return hipSuccess;
 	switch (j.T) {
-		case 2: return launch_fused_t<2, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
-		case 4: {
-			// sample the planes when the blocks can be loaded 16 bytes at a time (the slot encoder copes with any alignment)
-			const char* force = getenv("STENOS_EXP_INT32_LOOP"); // experiments: "slots" / "groups"
-			if (force && force[0] == 'g')
-				hipMemsetAsync(busy, 0xFF, 4, stream);
-			else if (!force && ((uintptr_t)j.src & 15u) == 0 && nsb * j.bps >= PROBE_SAMPLES)
-				hipLaunchKernelGGL(probe_planes, dim3(PROBE_SAMPLES), dim3(64), 0, stream, j.src, nsb * j.bps, busy);
-			hipError_t e = launch_fused_t<4, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
-			return e != hipSuccess ? e : launch_fused_t<4, true>(j, nsb, stage, desc, ticket, carry, busy, stream);
-		}
-		case 8: return launch_fused_t<8, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
-		default: return launch_fused_t<0, false>(j, nsb, stage, desc, ticket, carry, busy, stream);
+		case 2: return launch_fused_t<2>(j, nsb, stage, desc, ticket, carry, stream);
+		case 4: return launch_fused_t<4>(j, nsb, stage, desc, ticket, carry, stream);
+		case 8: return launch_fused_t<8>(j, nsb, stage, desc, ticket, carry, stream);
+		default: return launch_fused_t<0>(j, nsb, stage, desc, ticket, carry, stream);
 	}
 }
+// Superblocks [0, nsb) of the job (stream_supported), all of them full blocks with room for any encoding.  agg: nsb * 64
+// zeroed words, done and size: nsb zeroed words each, tickets: STREAM_MAX_SHARDS * 32 zeroed words, j.sb_off[0, nsb] zeroed; *carry
+// receives the frame offset behind them.
+template <uint32_t TT>
+static hipError_t launch_stream_t(const FrameJob& j, uint64_t nsb, uint32_t* agg, uint64_t* done, uint64_t* size, uint32_t* tickets, uint64_t* carry, hipStream_t stream)
+{
+	const size_t lds = STREAM_WAVES * make_unit_layout(TT).total + 64;
+	hipError_t e = hipFuncSetAttribute((const void*)encode_stream<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess)
+		return e;
+	const uint64_t groups_wanted = (nsb * 64 + STREAM_WAVES - 1) / STREAM_WAVES;
+	const uint64_t resident = (uint64_t)stenos_k_cu_count() * 8;
+	const uint32_t groups = (uint32_t)(groups_wanted < resident ? groups_wanted : resident);
+	const uint32_t shards = groups * STREAM_WAVES < STREAM_MAX_SHARDS ? groups * STREAM_WAVES : STREAM_MAX_SHARDS;
+	hipLaunchKernelGGL(encode_stream<TT>, dim3(groups + 1), dim3(64 * STREAM_WAVES), lds, stream, j, nsb, agg, done, size, tickets, carry, shards);
+	return hipGetLastError();
+}
+hipError_t stenos_k_launch_encode_stream(const FrameJob& j, uint64_t nsb, uint32_t* agg, uint64_t* done, uint64_t* size, uint32_t* tickets, uint64_t* carry,
+					 hipStream_t stream)
+{
+	if (nsb == 0)
+		return hipSuccess;
+	return j.T == 2 ? launch_stream_t<2>(j, nsb, agg, done, size, tickets, carry, stream) : launch_stream_t<4>(j, nsb, agg, done, size, tickets, carry, stream);
+}
+bool stenos_k_stream_supported(uint32_t T, uint32_t bps) { return stream_supported(bps, T); }
+size_t stenos_k_stream_words(uint64_t nsb) { return (size_t)nsb * 64 + STREAM_MAX_SHARDS * 32; } // agg + tickets, 32-bit words
+
 // the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)
 bool stenos_k_fused_supported(uint32_t T) { return FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 64 <= 160u * 1024u; }
 size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb) { return (size_t)nsb * FUSED_WAVES * fused_run_capacity(bps, T) + 64; }

@@ -16,7 +16,8 @@
 namespace codec {
 
 constexpr uint32_t SLOT2_BYTES = 256; // lane 16*s + r reads LDS bytes [16*lane, 16*lane + 16) of the slot area: no bank conflicts
-WV_HD uint32_t slot2_area(const Layout& L) { return L.aux; }
+// in a unit image (block_codec.h) the slots lie where the batch is going to be written, behind the 16-byte group it starts in
+WV_HD uint32_t slot2_area(const Layout& L) { return L.inplace ? L.out + 16u : L.aux; }
 
 // ---- element lanes: a block in registers -> its non-constant planes in slots slot, slot + 1, ... ---------------------
 // Byte k of the OR over all elements of (element ^ first element) is non-zero exactly when plane k is not constant
@@ -93,7 +94,7 @@ WV_FN uint32_t lz_distinct_keys_fast(Lds lds, const Layout& L, const U128& e)
 		const U32 v[4] = { e.x, e.y, e.z, e.w };
 		U32 addr[4];
 		for (int k = 0; k < 4; ++k) {
-			addr[k] = U32(L.out) + (mul24(v[k], U32(0xB1u * 4u)) & 0x3FCu);
+			addr[k] = U32(L.tab) + (mul24(v[k], U32(0xB1u * 4u)) & 0x3FCu);
 			lds_st32(lds, addr[k], lane + U32(64u * (uint32_t)k), in);
 		}
 		wave_sync();
@@ -101,7 +102,7 @@ WV_FN uint32_t lz_distinct_keys_fast(Lds lds, const Layout& L, const U128& e)
 			distinct += (uint32_t)__builtin_popcountll(ballot(in & (lds_ld32(lds, addr[k]) == lane + U32(64u * (uint32_t)k))));
 	});
 	wave_sync();
-	return distinct;
+	return first_lane_value(distinct); // the other lanes have not counted
 }
 
 // ---- row lanes ---------------------------------------------------------------------------------------------------------
@@ -273,15 +274,16 @@ WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T)
 }
 
 // OR a value that cannot straddle a dword (a nibble at a nibble-aligned bit position, a byte at a byte-aligned one) into the
-// zeroed image.  Lanes that have nothing to write OR a zero wherever their position points, inside the image's 2 KiB.
-WV_FN void put_small(Lds out, const U32& bitpos, const U32& value, const Pred& p)
+// zeroed image.  Lanes that have nothing to write OR a zero into a dword of their own (`own`, a byte offset: one shared
+// address would serialise the wave in the LDS atomic unit).
+WV_FN void put_small(Lds out, const U32& bitpos, const U32& value, const Pred& p, const U32& own)
 {
-	lds_or32_all(out, (bitpos >> 3) & 0x7FCu, sel(p, value << (bitpos & 31u), U32(0u)));
+	lds_or32_all(out, sel(p, (bitpos >> 3) & ~3u, own), sel(p, value << (bitpos & 31u), U32(0u)));
 }
 // the same for up to 32 bits at any bit position
-WV_FN void put_bits(Lds out, const U32& bitpos, const U32& value, const Pred& p)
+WV_FN void put_bits(Lds out, const U32& bitpos, const U32& value, const Pred& p, const U32& own)
 {
-	const U32 a = (bitpos >> 3) & 0x7FCu, sh = bitpos & 31u, v = sel(p, value, U32(0u));
+	const U32 a = sel(p, (bitpos >> 3) & ~3u, own), sh = bitpos & 31u, v = sel(p, value, U32(0u));
 	lds_or32_all(out, a, v << sh);
 	lds_or32_all(out, a + 4u, sel(sh == U32(0u), U32(0u), v >> (U32(32u) - sh)));
 }
@@ -302,6 +304,7 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	const U32 H(0x80808080u);
 	Lds out = lds + L.out;
 	const uint32_t hs = header_bytes(T);
+	const U32 own = lane * 4u; // where lanes with nothing to write OR their zeros
 	WV_MARK("emit_nibbles");
 	const Pred second = P.blk != U32(0u);
 	const U32 bbase = sel(second, U32(base1), U32(base0));
@@ -316,12 +319,12 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 		const U32 byte = (P.first >> (plane << 3)) & 0xFFu;
 		const U32 where = sel(follows, pbase + R.size + after, bbase + U32(hs) + before);
 		const Pred nib = r == U32(0u);
-		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type, byte), P.valid & (nib | follows | leads));
+		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type, byte), P.valid & (nib | follows | leads), own);
 	}
 	for (uint32_t i = 0; i < B.nblk; ++i) // a block without a slot: its SAME bytes (the type nibbles are all 0)
 		if (B.act[i] == 0) {
 			const U32 byte = (U32(B.first[i]) >> (lane << 3)) & 0xFFu;
-			put_small(out, (U32((i ? base1 : base0) + hs) + lane) * 8u, byte, lane < U32(T));
+			put_small(out, (U32((i ? base1 : base0) + hs) + lane) * 8u, byte, lane < U32(T), own);
 		}
 	if (B.nslots == 0) {
 		wave_sync();
@@ -331,15 +334,15 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	const U32 hdr = R.hdr;
 	const Pred israw = P.valid & (R.type == U32(PLANE_RAW));
 	const Pred normal = P.valid & !israw;
-	put_small(out, pbase * 8u + r * 4u, hdr, normal); // (:768-779, 758-762)
-	put_small(out, (pbase + R.minpos) * 8u, R.minb ^ 0x80u, normal & R.emitmin);
+	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
+	put_small(out, (pbase + R.minpos) * 8u, R.minb ^ 0x80u, normal & R.emitmin, own);
 	{
 		// mins rle mask (:765): bit r = min equals previous min
 		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
 		if (any(isnrle)) {
 			const uint64_t eqb = ballot(R.eq);
 			const U32 m16 = row_select4((uint32_t)eqb & 0xFFFFu, (uint32_t)(eqb >> 16) & 0xFFFFu, (uint32_t)(eqb >> 32) & 0xFFFFu, (uint32_t)(eqb >> 48));
-			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)));
+			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
 		}
 	}
 	WV_MARK("emit_plane");
@@ -357,7 +360,6 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 		pk[k] = pack4v(sel(usedelta, R.sd[k], R.sb[k]) - mins, bits);
 	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
 	const Pred anyw = rawrow | packed;
-	const U32 own = lane * 4u; // where lanes without a row payload OR their zeros
 	const U32 s0lo = sel(rawrow, R.sb[0] ^ H, sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
 	const U32 s0hi = sel(rawrow, R.sb[1] ^ H, sel(packed, pk[1] >> ish4, U32(0u)));
 	const U32 s1lo = sel(rawrow, R.sb[2] ^ H, sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
@@ -376,10 +378,10 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 			const U32 f = zero_mask_to_bits(z);
 			f16 = f16 | (f << U32(4u * (uint32_t)k));
 			const U32 nlit = U32(4u) - popc(f);
-			put_bits(out, lp * 8u, compact_unflagged(sel(is7, R.sb[k], R.sd[k]) ^ H, f), rle & (nlit != U32(0u)));
+			put_bits(out, lp * 8u, compact_unflagged(sel(is7, R.sb[k], R.sd[k]) ^ H, f), rle & (nlit != U32(0u)), own);
 			lp = lp + nlit;
 		}
-		put_bits(out, rbase * 8u, f16, rle);
+		put_bits(out, rbase * 8u, f16, rle, own);
 	}
 	WV_MARK("emit_end");
 	wave_sync();

@@ -127,11 +127,13 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 	const uint32_t r = rs.pos & 15u;
 	const uint32_t groups = (r + n) >> 4;
 	uint8_t* g = rs.base + (rs.pos - r);
+#ifndef STENOS_EXP_NOSTAGE
 	for (uint32_t o = 0; o < groups; o += 64) {
 		U32 k = U32(o) + lane;
 		Pred p = k < U32(groups);
 		gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
 	}
+#endif
 	// the group behind them (its bytes past the encoding are zero) waits in front of the image
 	Pred t = lane < U32(4u);
 	U32 a = sel(t, lane, U32(0u)) * 4u;
@@ -148,16 +150,29 @@ WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 	gst8(rs.base + (rs.pos - r), lane, lds_ld8(lds, U32(out - 16u) + sel(t, lane, U32(0u))), t);
 }
 
-// `nblocks` full blocks at src -> their encodings, back to back, at stage (16-byte aligned, room for
-// nblocks * max_block_bytes(T) + 16).  Ample capacity is assumed (the mini-LZ is always tried), which is
-// what the reference does for every superblock but the ones at the very end of a tight buffer.
-// slots: bytesoftype 2 and 4 go through the plane slots (two blocks per pass); false: the plane-group loop at the bottom,
-// which is the shorter way for int32 data whose blocks have three or four non-constant planes (kernels.hip, probe_planes).
-WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true)
-{
+// Where the encodings of consecutive blocks go.  A sink names the image the next block is written into (at), the byte of
+// that image it starts at (base, < 16) and takes the bytes over once they are written (append).
+struct StreamSink { // a contiguous stream in HBM (RunStream)
 	RunStream rs;
-	rs.base = stage;
-	rs.pos = 0;
+	WV_MFN Layout at(const Layout& L) const { return L; }
+	WV_MFN uint32_t base() const { return rs.pos & 15u; }
+	WV_MFN void append(Lds lds, const Layout& L, uint32_t n) { stream_append(rs, lds, L.out, n); }
+};
+struct UnitSink { // the unit image of make_unit_layout: blocks stay in LDS, back to back
+	uint32_t pos;
+	WV_MFN Layout at(const Layout& L) const { return image_at(L, pos); }
+	WV_MFN uint32_t base() const { return pos & 15u; }
+	WV_MFN void append(Lds, const Layout&, uint32_t n) { pos += n; }
+};
+
+// `nblocks` full blocks at src -> their encodings, back to back, into the sink.  Ample capacity is assumed (the
+// mini-LZ is always tried), which is what the reference does for every superblock but the ones at the very end of a
+// tight buffer.
+// slots: bytesoftype 2 and 4 go through the plane slots (slot_codec.h, up to two blocks per pass); false: the plane-group
+// loop at the bottom.
+template <class Sink>
+WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, bool slots)
+{
 	if (slots && (T == 2 || T == 4)) {
 		// Planes in slots (slot_codec.h): the non-constant planes of a block, and of its successor when they fit into
 		// the four slots together, are analysed and written by row lanes in one pass.
@@ -178,6 +193,7 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 				if (has_b)
 					eb = load_raw_block(b, T);
 				WV_MARK("block_begin");
+				const Layout M = sink.at(L);
 				SlotBatch B;
 				uint32_t keys0 = 0, keys1 = 0; // distinct hash keys at the head of each block (first rejection test of the mini-LZ)
 				{
@@ -187,9 +203,6 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 					B.nact0 = B.nslots = sa.nact;
 					B.act[1] = B.first[1] = 0;
 				}
-				if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
-					keys0 = lz_distinct_keys_fast(lds, L, ea.e);
-				write_slots_fast(lds, L, ea, T, B.act[0], 0);
 				if (has_b && B.nact0 <= 2) {
 					const SameScan sb = scan_same_fast(eb, T);
 					if (B.nact0 + sb.nact <= 4) {
@@ -197,16 +210,21 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 						B.first[1] = sb.first;
 						B.nslots = B.nact0 + sb.nact;
 						nblk = 2;
-						if (T == 4 && sb.nact >= 2)
-							keys1 = lz_distinct_keys_fast(lds, L, eb.e);
-						write_slots_fast(lds, L, eb, T, sb.act, B.nact0);
 					}
 				}
+				// (the key counts use the mini-LZ's table area, which the slots of a unit image may overlap: counts first)
+				if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
+					keys0 = lz_distinct_keys_fast(lds, M, ea.e);
+				if (T == 4 && nblk > 1 && B.nslots - B.nact0 >= 2)
+					keys1 = lz_distinct_keys_fast(lds, M, eb.e);
+				write_slots_fast(lds, M, ea, T, B.act[0], 0);
+				if (nblk > 1)
+					write_slots_fast(lds, M, eb, T, B.act[1], B.nact0);
 				B.nblk = nblk;
 				wave_sync();
 				SlotRows R;
 				if (B.nslots)
-					slot_rows_analyse(lds, L, R);
+					slot_rows_analyse(lds, M, R);
 				else { // only constant planes: nothing to measure
 					for (int k = 0; k < 4; ++k)
 						R.sb[k] = R.sd[k] = U32(0u);
@@ -222,12 +240,12 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 						lzq |= 2u;
 				}
 				if (!lzq) {
-					const uint32_t base = rs.pos & 15u, size0 = hs + B.full[0], size1 = nblk > 1 ? hs + B.full[1] : 0u;
+					const uint32_t base = sink.base(), size0 = hs + B.full[0], size1 = nblk > 1 ? hs + B.full[1] : 0u;
 					WV_MARK("image_reset");
-					image_reset(lds, L, base, size0 + size1);
-					slot_rows_emit(lds, L, T, R, P, B, base, base + size0);
+					image_reset(lds, M, base, size0 + size1);
+					slot_rows_emit(lds, M, T, R, P, B, base, base + size0);
 					WV_MARK("stream_append");
-					stream_append(rs, lds, L.out, size0 + size1);
+					sink.append(lds, M, size0 + size1);
 					WV_MARK("block_end");
 					i += nblk;
 					continue;
@@ -237,22 +255,81 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 			for (uint32_t q = 0; q < nblk; ++q) {
 				load_block(lds, L.in, q ? b : a, bs);
 				wave_sync();
-				const BlockInfo r = encode_full_block(lds, L, T, true, rs.pos & 15u);
-				stream_append(rs, lds, L.out, r.size);
+				const Layout M = sink.at(L);
+				const BlockInfo r = encode_full_block(lds, M, T, true, sink.base());
+				sink.append(lds, M, r.size);
 			}
 			i += nblk;
 		}
-		stream_flush(rs, lds, L.out);
-		return rs.pos;
+		return;
 	}
 	for (uint32_t i = 0; i < nblocks; ++i) {
 		load_block(lds, L.in, src + (uint64_t)i * (256 * T), 256 * T);
 		wave_sync();
-		BlockInfo r = encode_full_block(lds, L, T, true, rs.pos & 15u);
-		stream_append(rs, lds, L.out, r.size);
+		const Layout M = sink.at(L);
+		const BlockInfo r = encode_full_block(lds, M, T, true, sink.base());
+		sink.append(lds, M, r.size);
 	}
-	stream_flush(rs, lds, L.out);
-	return rs.pos;
+}
+
+// ... into a staging stream at stage (16-byte aligned, room for nblocks * max_block_bytes(T) + 16); returns the bytes
+WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true)
+{
+	StreamSink sink;
+	sink.rs.base = stage;
+	sink.rs.pos = 0;
+	encode_blocks_to(sink, lds, L, T, src, nblocks, slots);
+	stream_flush(sink.rs, lds, L.out);
+	return sink.rs.pos;
+}
+// ... into the unit image (L from make_unit_layout): bytes [0, n) of it; returns n
+WV_FN uint32_t encode_unit(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks)
+{
+	UnitSink sink;
+	sink.pos = 0;
+	encode_blocks_to(sink, lds, L, T, src, nblocks, true);
+	return sink.pos;
+}
+
+// The n bytes of a unit image -> g (any alignment), with 16-byte stores where whole 16-byte groups of the destination are
+// covered and byte stores at both ends, so neighbouring units can write their own bytes at the same time.
+WV_FN void store_image(uint8_t* g, Lds lds, uint32_t img, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t head = (uint32_t)((16u - ((uintptr_t)g & 15u)) & 15u);
+	const uint32_t h = head < n ? head : n;
+	{
+		Pred p = lane < U32(h);
+		gst8(g, lane, lds_ld8(lds, U32(img) + sel(p, lane, U32(0u))), p);
+	}
+	const uint32_t groups = (n - h) >> 4;
+	const uint32_t sh = (h & 3u) * 8u, a0 = img + (h & ~3u);
+	for (uint32_t o = 0; o < groups; o += 64) {
+		const U32 k = U32(o) + lane;
+		const Pred p = k < U32(groups);
+		const U32 a = U32(a0) + sel(p, k, U32(0u)) * 16u;
+		const U32 w0 = lds_ld32(lds, a), w1 = lds_ld32(lds, a + 4u), w2 = lds_ld32(lds, a + 8u), w3 = lds_ld32(lds, a + 12u);
+		U128 v;
+		if (sh) {
+			const U32 w4 = lds_ld32(lds, a + 16u);
+			v.x = (w0 >> U32(sh)) | (w1 << U32(32u - sh));
+			v.y = (w1 >> U32(sh)) | (w2 << U32(32u - sh));
+			v.z = (w2 >> U32(sh)) | (w3 << U32(32u - sh));
+			v.w = (w3 >> U32(sh)) | (w4 << U32(32u - sh));
+		}
+		else {
+			v.x = w0;
+			v.y = w1;
+			v.z = w2;
+			v.w = w3;
+		}
+		gst128(g + h, k * 16u, v, p);
+	}
+	const uint32_t done = h + groups * 16;
+	{
+		Pred p = lane < U32(n - done);
+		gst8(g + done, lane, lds_ld8(lds, U32(img + done) + sel(p, lane, U32(0u))), p);
+	}
 }
 
 // HBM -> HBM copy of n bytes by one wave with 16-byte stores; src may be read up to 31 bytes past src + n

@@ -20,6 +20,7 @@
 // ------------------------------------------------------------------------------------------------
 #include <string.h>
 #define WV_FN static inline
+#define WV_MFN inline
 #define WV_HD static inline
 #define WV_MARK(name)
 namespace wv {
@@ -444,6 +445,7 @@ WV_FN void lds_st128(Lds m, const U32& a, const U128& v, const Pred& p)
 // ------------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
 #define WV_FN static __device__ __forceinline__
+#define WV_MFN __device__ __forceinline__
 #define WV_HD static __host__ __device__ __forceinline__
 // a comment line in the generated ISA (tools/isa_regions.py counts the instructions between marks); no code
 #define WV_MARK(name) asm volatile("; MARK " name)
@@ -688,6 +690,16 @@ WV_FN void lds_st128(Lds m, U32 a, const U128& v, Pred p)
 namespace wv {
 
 WV_FN bool any(const Pred& p) { return ballot(p) != 0; }
+// A value the first lane holds, as a wave-uniform scalar: needed for scalars that were updated inside lanes_below(), which
+// on the device only the participating lanes have seen.
+WV_FN uint32_t first_lane_value(uint32_t x)
+{
+#ifdef WV_HOST_EMULATION
+	return x;
+#else
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+#endif
+}
 // Run f(p) for the first n lanes only: on the device one divergent region (p is all-true inside it), on the host a predicate.
 template <class F>
 WV_FN void lanes_below(uint32_t n, F f)
