@@ -35,8 +35,7 @@ struct Layout {
 	uint32_t lz;      // mini-LZ chain count*4 + cur count*4, on top of aux; its 256-entry table uses the not yet written image
 	uint32_t skip;    // mini-LZ: one bit per group that was left raw (32 bytes)
 	uint32_t tab;     // 1 KiB for the tables of the mini-LZ (hash table, counters and bitmaps of its rejection tests): the image, which is
-	                  // only written once they are dead; in a unit image (below) the part behind what earlier blocks have written
-	uint32_t inplace; // unit image (make_unit_layout): blocks are appended where their predecessor ended, see image_reset
+	                  // only written once they are dead
 	uint32_t total;
 };
 
@@ -75,46 +74,7 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	o += scratch;
 	L.total = align16(o);
 	L.tab = L.out;
-	L.inplace = 0;
 	return L;
-}
-
-// Unit images (bytesoftype 2 and 4, the streaming encoder of kernels.hip): a wavefront encodes UNIT_BYTES of input, 2 KiB,
-// into one image, block after block, and stores the image once its place in the frame is known -- while it already
-// fills the second image with the next unit (unit_image()).  Block k+1 is encoded with a layout whose image starts at
-// the 16-byte group in which block k ended (image_at); the plane slots of slot_codec.h lie in the part of the image the
-// batch is about to be written to (they are dead by then), the mini-LZ tables 1040 bytes into the image, behind anything
-// the earlier blocks of the unit can have written when a block asks for them.
-constexpr uint32_t UNIT_BYTES = 2048;
-WV_HD uint32_t unit_blocks(uint32_t T) { return UNIT_BYTES / (256 * T); }
-WV_HD uint32_t unit_image_bytes(uint32_t T) { return align16(unit_blocks(T) * (256 * T + header_bytes(T) + 1)) + 48; } // + what emission writes past the end
-WV_HD Layout make_unit_layout(uint32_t T)
-{
-	Layout L = make_layout(T, true);
-	const uint32_t grow = 2 * unit_image_bytes(T) - out_capacity(T);
-	L.rowinfo += grow;
-	L.plinfo += grow;
-	L.skip += grow;
-	L.aux += grow;
-	L.lz += grow;
-	L.total += grow;
-	L.tab = L.out + 1040;
-	L.inplace = 1;
-	return L;
-}
-// the layout for unit image k (0 or 1)
-WV_HD Layout unit_image(const Layout& L, uint32_t T, uint32_t k)
-{
-	Layout M = L;
-	M.out = L.out + k * unit_image_bytes(T);
-	M.tab = M.out + 1040;
-	return M;
-}
-WV_HD Layout image_at(const Layout& L, uint32_t pos)
-{
-	Layout M = L;
-	M.out = L.out + (pos & ~15u);
-	return M;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -648,19 +608,8 @@ WV_FN void lds_zero(Lds lds, uint32_t off, uint32_t bytes)
 // Zeroed image for an encoding of `size` bytes that starts at byte `base` (< 16) of the image.  A block that is
 // appended to a stream (superblock_codec.h, RunStream) starts behind the bytes of its predecessor that did not fill
 // a 16-byte group: they wait, padded with zeros, in the 16 bytes in front of the image and become its first group.
-// In a unit image (L.inplace) those bytes are where the predecessor wrote them and stay there.
 WV_FN void image_reset(Lds lds, const Layout& L, uint32_t base, uint32_t size)
 {
-	if (L.inplace && base) {
-		lds_zero(lds, L.out + 16u, align16(base + size));
-		const U32 lane = lane_id();
-		const Pred p = lane < U32(4u);
-		const U32 a = sel(p, lane, U32(0u)) * 4u;
-		const U32 keep = sel(a + 4u <= U32(base), U32(0xFFFFFFFFu), sel(a >= U32(base), U32(0u), (U32(1u) << ((U32(base) - a) << 3)) - 1u));
-		lds_st32(lds, U32(L.out) + a, lds_ld32(lds, U32(L.out) + a) & keep, p);
-		wave_sync();
-		return;
-	}
 	lds_zero(lds, L.out, align16(base + size) + 16u);
 	if (base) {
 		const U32 lane = lane_id();

@@ -140,19 +140,19 @@ struct HostBuf {
 	uint8_t* data() const { return p; }
 };
 
-// STENOS_HOST_TRACE=1: wall-clock of the host phases of the strategy layer on stderr (diagnostics)
+// builds with -DSTENOS_HOST_TRACE: wall-clock of the host phases of the strategy layer on stderr (diagnostics)
 struct PhaseTrace {
-	bool on;
-	std::chrono::steady_clock::time_point t;
-	PhaseTrace() : on(getenv("STENOS_HOST_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+#ifdef STENOS_HOST_TRACE
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
 	void mark(const char* what)
 	{
-		if (!on)
-			return;
 		const auto n = std::chrono::steady_clock::now();
 		fprintf(stderr, "[stenos] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
 		t = n;
 	}
+#else
+	void mark(const char*) {}
+#endif
 };
 
 inline void put_le(uint8_t* p, uint64_t v, int n)
@@ -206,16 +206,6 @@ struct stenos_context_s {
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; // encode start/stop, decode start/stop
 	bool ev_valid[2] = { false, false };
 	// second stream and events for overlapping the pack of one chunk with the encoding of the next
-	hipStream_t aux_stream = nullptr;
-	hipEvent_t ev_chunk = nullptr, ev_join = nullptr;
-	bool ensure_aux()
-	{
-		if (aux_stream)
-			return true;
-		return hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) == hipSuccess &&
-		       hipEventCreateWithFlags(&ev_chunk, hipEventDisableTiming) == hipSuccess &&
-		       hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess;
-	}
 
 	bool device_ready()
 	{
@@ -241,12 +231,6 @@ struct stenos_context_s {
 		for (hipEvent_t e : ev)
 			if (e)
 				(void)hipEventDestroy(e);
-		if (ev_chunk)
-			(void)hipEventDestroy(ev_chunk);
-		if (ev_join)
-			(void)hipEventDestroy(ev_join);
-		if (aux_stream)
-			(void)hipStreamDestroy(aux_stream);
 	}
 	void mark(int idx, hipStream_t stream)
 	{
@@ -380,42 +364,22 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	};
 
 	uint64_t* d_carry = (uint64_t*)(misc + 24);
-	// Safe superblocks that consist of full blocks go through the fused kernel (encode + offsets + store in one
-	// launch); STENOS_NO_FUSED=1 sends them through encode / plan / scan / pack like the rest.
+	// Safe superblocks that consist of full blocks go through the fused kernel (encode + offsets + store in one launch).
 	// (offset 0 means "not published yet" to the fused kernel, so frames without a header stay on the other path)
 	uint64_t s_fused = 0;
-	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T) && !getenv("STENOS_NO_FUSED"))
+	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T))
 		s_fused = f.nfull / f.bps < s_tight ? f.nfull / f.bps : s_tight;
 	// One arena serves both: the staging streams of the fused superblocks, then (the fused kernel is done by
 	// then) the 16-byte aligned slots of the remaining blocks, addressed by their absolute block number.
 	const uint64_t b_unfused = first_block(s_fused);
-	// bytesoftype 2 and 4 stream their encodings from LDS to the frame (kernels.hip, encode_stream); the other sizes
-	// stage them in the arena first (encode_superblocks)
-	const bool streaming = s_fused && stenos_k_stream_supported((uint32_t)T, f.bps);
 	if (level >= 1) {
-		const size_t stage_bytes = s_fused && !streaming ? stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused) : 0;
+		const size_t stage_bytes = s_fused ? stenos_k_fused_stage_bytes((uint32_t)T, f.bps, s_fused) : 0;
 		const size_t slot_bytes = (size_t)(nblocks_all - b_unfused + 1) * stride;
 		if (!ctx->slots.ensure(stage_bytes > slot_bytes ? stage_bytes : slot_bytes))
 			return STENOS_ERROR_ALLOC;
 		j.slots = ctx->slots.as<uint8_t>() - b_unfused * (uint64_t)stride;
 	}
-	if (streaming) {
-		// chain: [size words of the scanner: s_fused + 2][done words: s_fused][unit words and ticket counters]
-		const size_t words64 = (s_fused + 2) + s_fused + (stenos_k_stream_words(s_fused) + 1) / 2;
-		if (!ctx->chain.ensure(words64 * 8))
-			return STENOS_ERROR_ALLOC;
-		uint64_t* size = ctx->chain.as<uint64_t>();
-		uint64_t* done = size + s_fused + 2;
-		uint32_t* agg = (uint32_t*)(done + s_fused);
-		uint32_t* tickets = agg + s_fused * 64;
-		if (stenos_k_launch_init(misc, header, size, words64, j.sb_off, s_fused + 8, stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		ctx->mark(0, stream);
-		if (stenos_k_launch_encode_stream(j, s_fused, agg, done, size, tickets, d_carry, stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		ctx->mark(1, stream);
-	}
-	else if (s_fused) {
+	if (s_fused) {
 		if (!ctx->chain.ensure((s_fused + 2) * 8))
 			return STENOS_ERROR_ALLOC;
 		uint64_t* desc = ctx->chain.as<uint64_t>() + 1; // word 0: ticket counter
@@ -429,34 +393,17 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	else if (stenos_k_launch_init(misc, header, nullptr, 0, nullptr, 0, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	if (s_tight > s_fused) {
-		// Measured on MI355X (8 GiB int32): overlapping the pack of chunk k with the encoding of chunk k+1 on a
-		// second stream gains nothing (748-802 GB/s against 725-764 GB/s for one chunk; chunks below 128 MiB are
-		// launch-bound), so by default the zone is one chunk.  STENOS_CHUNK_MIB enables the chunked form.
-		uint64_t csb = s_tight - s_fused;
-		if (const char* e = getenv("STENOS_CHUNK_MIB"))
-			if (atoi(e) > 0)
-				csb = ((uint64_t)atoi(e) << 20) / f.sb;
-		if (csb == 0)
-			csb = 1;
-		const bool overlap = s_tight - s_fused > csb && ctx->ensure_aux();
-		hipStream_t s2 = overlap ? ctx->aux_stream : stream;
-		if (overlap && s_fused && (hipEventRecord(ctx->ev_chunk, stream) != hipSuccess || hipStreamWaitEvent(s2, ctx->ev_chunk, 0) != hipSuccess))
+		// safe superblocks the fused kernel does not take (bytesoftype too large for its LDS budget, frames without a header):
+		// one encode / plan / scan / pack sequence.  (Overlapping the pack of one chunk with the encoding of the next on a
+		// second stream was measured on MI355X and gains nothing.)
+		if (s_fused == 0)
+			ctx->mark(0, stream); // kernel timing: the encode_blocks launch of the safe zone
+		if (level >= 1 && stenos_k_launch_encode(j, first_block(s_fused), first_block(s_tight), stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
-		for (uint64_t s0 = s_fused; s0 < s_tight; s0 += csb) {
-			const uint64_t s1 = s0 + csb < s_tight ? s0 + csb : s_tight;
-			if (s0 == 0)
-				ctx->mark(0, stream); // kernel timing: the first (normally only) encode_blocks launch of the safe zone
-			if (level >= 1 && stenos_k_launch_encode(j, first_block(s0), first_block(s1), stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
-			if (s0 == 0)
-				ctx->mark(1, stream);
-			if (overlap && (hipEventRecord(ctx->ev_chunk, stream) != hipSuccess || hipStreamWaitEvent(s2, ctx->ev_chunk, 0) != hipSuccess))
-				return STENOS_ERROR_UNDEFINED;
-			if (stenos_k_launch_plan(j, s0, s1, s2) != hipSuccess || stenos_k_launch_scan(j, s0, s1, d_carry, s2) != hipSuccess ||
-			    stenos_k_launch_pack(j, s0, s1, s2) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
-		}
-		if (overlap && (hipEventRecord(ctx->ev_join, s2) != hipSuccess || hipStreamWaitEvent(stream, ctx->ev_join, 0) != hipSuccess))
+		if (s_fused == 0)
+			ctx->mark(1, stream);
+		if (stenos_k_launch_plan(j, s_fused, s_tight, stream) != hipSuccess || stenos_k_launch_scan(j, s_fused, s_tight, d_carry, stream) != hipSuccess ||
+		    stenos_k_launch_pack(j, s_fused, s_tight, stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 	}
 	// tail zone
@@ -836,13 +783,15 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		choice.assign(cnt, 0);
 		parallel_for(cnt, [&](uint64_t k) { choice[k] = decide(s0 + k); });
 		trace.mark("estimates");
-		if (trace.on) {
+#ifdef STENOS_HOST_TRACE
+		{
 			unsigned h[5] = { 0, 0, 0, 0, 0 };
 			for (uint64_t k = 0; k < cnt; ++k)
 				++h[choice[k]];
 			fprintf(stderr, "[stenos]   superblocks %llu: tiny %u, block codec %u, zstd %u, transposed %u, transposed+delta %u\n", (unsigned long long)cnt, h[0], h[1],
 				h[2], h[3], h[4]);
 		}
+#endif
 		// byte delta of the whole transposed superblock on the GPU for the choice-4 ones (stenos.cpp:646)
 		dslot.assign(cnt, 0);
 		uint64_t nd = 0;

@@ -26,7 +26,6 @@ struct DecodeArgs {
 };
 
 uint32_t stenos_k_cu_count();
-uint32_t stenos_k_waves_per_cu(size_t lds_bytes);
 size_t stenos_k_encode_lds_bytes(uint32_t T);
 size_t stenos_k_decode_lds_bytes(uint32_t T);
 uint32_t stenos_k_slot_stride(uint32_t T);
@@ -44,10 +43,7 @@ hipError_t stenos_k_launch_shuffle(const uint8_t* src, uint8_t* dst, uint32_t T,
 hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1, uint64_t n1, uint64_t* z2, uint64_t n2, hipStream_t stream);
 hipError_t stenos_k_launch_encode_fused(const codec::FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream);
 bool stenos_k_fused_supported(uint32_t T);
-hipError_t stenos_k_launch_encode_stream(const codec::FrameJob& j, uint64_t nsb, uint32_t* agg, uint64_t* done, uint64_t* size, uint32_t* tickets, uint64_t* carry,
-					 hipStream_t stream);
-bool stenos_k_stream_supported(uint32_t T, uint32_t bps);
-size_t stenos_k_stream_words(uint64_t nsb);
+uint32_t stenos_k_fused_groups(uint64_t nsb);
 size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb);
 hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t bytes, bool inverse, hipStream_t stream);
 hipError_t stenos_k_launch_shuffle_superblocks(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t sb, uint64_t total, hipStream_t stream);

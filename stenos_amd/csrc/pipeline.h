@@ -284,9 +284,6 @@ WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, 
 		// superblock header [code][csize:3 LE] (stenos.cpp:613-615)
 		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
 	}
-#ifdef STENOS_EXP_NOCOPY
-	return;
-#endif
 	if (code == 1) {
 		uint32_t before = 0;
 		for (uint32_t k = 0; k < w; ++k)
@@ -298,45 +295,6 @@ WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, 
 		fused_run_range(j.bps, w, &b0, &b1);
 		const uint32_t bs = 256 * j.T;
 		copy_g2g(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
-	}
-}
-
-// ---- streaming path (bytesoftype 2 and 4): no staging in HBM ----------------------------------------
-//
-// A superblock is cut into units of UNIT_BYTES input bytes (block_codec.h); a wavefront encodes a unit into its LDS
-// image (superblock_codec.h, encode_unit), publishes the bytes it takes, learns the bytes of the other units of the
-// superblock and the superblock's frame offset (kernels.hip, encode_stream) and stores the image where it belongs.
-WV_HD uint32_t stream_units(uint32_t bps, uint32_t T) { return bps / unit_blocks(T); } // units per superblock
-WV_HD bool stream_supported(uint32_t bps, uint32_t T) { return (T == 2 || T == 4) && bps % unit_blocks(T) == 0 && stream_units(bps, T) == 64; }
-
-// Unit i of superblock s, whose image holds n bytes; prefix: bytes of the units before it, total: of all units of the
-// superblock; off: frame offset of the superblock's header.
-WV_FN void unit_store(const FrameJob& j, Lds lds, const Layout& L, uint64_t s, uint32_t i, uint64_t off, uint32_t prefix, uint32_t total, uint32_t n)
-{
-	const U32 lane = lane_id();
-	const uint32_t code = total > j.sb_bytes ? 6u : 1u; // result > bytes -> memcpy (stenos.cpp:609-610); equal is kept
-	const uint32_t csize = code == 1 ? total : j.sb_bytes;
-	uint8_t* base = j.dst + off;
-	if (i == 0) {
-		if (s == 0 && j.shift_byte != 0xFFFFFFFFu) { // frame header: [shift][bytes:7 LE] (+ [superblock size:4 LE]), stenos.cpp:862-874
-			const uint64_t v = (uint64_t)j.shift_byte | (j.total_bytes << 8);
-			gst8(j.dst, lane, (U32((uint32_t)v) >> ((lane & 3u) << 3)), lane < U32(4u));
-			gst8(j.dst, lane, (U32((uint32_t)(v >> 32)) >> ((lane & 3u) << 3)), (lane >= U32(4u)) & (lane < U32(8u)));
-			if (j.shift_byte == 255)
-				gst8(j.dst + 8, lane, U32(j.sb_bytes) >> ((lane & 3u) << 3), lane < U32(4u));
-		}
-		// superblock header [code][csize:3 LE] (stenos.cpp:613-615)
-		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
-	}
-	if (code == 1)
-		store_image(base + 4 + prefix, lds, L.out, n);
-	else { // the unit's input bytes as they are (stenos.cpp:363-374)
-		const uint8_t* raw = j.src + s * (uint64_t)j.sb_bytes + (uint64_t)i * UNIT_BYTES;
-		uint8_t* to = base + 4 + (uint64_t)i * UNIT_BYTES;
-		if ((((uintptr_t)raw) & 15u) == 0)
-			copy_g2g_wide(to, raw, UNIT_BYTES); // aligned source, whole 16-byte groups: nothing is read past the unit
-		else
-			copy_g2g(to, raw, UNIT_BYTES);
 	}
 }
 

@@ -16,8 +16,7 @@
 namespace codec {
 
 constexpr uint32_t SLOT2_BYTES = 256; // lane 16*s + r reads LDS bytes [16*lane, 16*lane + 16) of the slot area: no bank conflicts
-// in a unit image (block_codec.h) the slots lie where the batch is going to be written, behind the 16-byte group it starts in
-WV_HD uint32_t slot2_area(const Layout& L) { return L.inplace ? L.out + 16u : L.aux; }
+WV_HD uint32_t slot2_area(const Layout& L) { return L.aux; }
 
 // ---- element lanes: a block in registers -> its non-constant planes in slots slot, slot + 1, ... ---------------------
 // Byte k of the OR over all elements of (element ^ first element) is non-zero exactly when plane k is not constant

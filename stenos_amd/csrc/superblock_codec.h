@@ -127,13 +127,11 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 	const uint32_t r = rs.pos & 15u;
 	const uint32_t groups = (r + n) >> 4;
 	uint8_t* g = rs.base + (rs.pos - r);
-#ifndef STENOS_EXP_NOSTAGE
 	for (uint32_t o = 0; o < groups; o += 64) {
 		U32 k = U32(o) + lane;
 		Pred p = k < U32(groups);
 		gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
 	}
-#endif
 	// the group behind them (its bytes past the encoding are zero) waits in front of the image
 	Pred t = lane < U32(4u);
 	U32 a = sel(t, lane, U32(0u)) * 4u;
@@ -157,12 +155,6 @@ struct StreamSink { // a contiguous stream in HBM (RunStream)
 	WV_MFN Layout at(const Layout& L) const { return L; }
 	WV_MFN uint32_t base() const { return rs.pos & 15u; }
 	WV_MFN void append(Lds lds, const Layout& L, uint32_t n) { stream_append(rs, lds, L.out, n); }
-};
-struct UnitSink { // the unit image of make_unit_layout: blocks stay in LDS, back to back
-	uint32_t pos;
-	WV_MFN Layout at(const Layout& L) const { return image_at(L, pos); }
-	WV_MFN uint32_t base() const { return pos & 15u; }
-	WV_MFN void append(Lds, const Layout&, uint32_t n) { pos += n; }
 };
 
 // `nblocks` full blocks at src -> their encodings, back to back, into the sink.  Ample capacity is assumed (the
@@ -212,8 +204,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 						nblk = 2;
 					}
 				}
-				// (the key counts use the mini-LZ's table area, which the slots of a unit image may overlap: counts first)
-				if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
+								if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
 					keys0 = lz_distinct_keys_fast(lds, M, ea.e);
 				if (T == 4 && nblk > 1 && B.nslots - B.nact0 >= 2)
 					keys1 = lz_distinct_keys_fast(lds, M, eb.e);
@@ -282,58 +273,64 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 	stream_flush(sink.rs, lds, L.out);
 	return sink.rs.pos;
 }
-// ... into the unit image (L from make_unit_layout): bytes [0, n) of it; returns n
-WV_FN uint32_t encode_unit(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks)
-{
-	UnitSink sink;
-	sink.pos = 0;
-	encode_blocks_to(sink, lds, L, T, src, nblocks, true);
-	return sink.pos;
-}
-
-// The n bytes of a unit image -> g (any alignment), with 16-byte stores where whole 16-byte groups of the destination are
-// covered and byte stores at both ends, so neighbouring units can write their own bytes at the same time.
-WV_FN void store_image(uint8_t* g, Lds lds, uint32_t img, uint32_t n)
-{
-	const U32 lane = lane_id();
-	const uint32_t head = (uint32_t)((16u - ((uintptr_t)g & 15u)) & 15u);
-	const uint32_t h = head < n ? head : n;
-	{
-		Pred p = lane < U32(h);
-		gst8(g, lane, lds_ld8(lds, U32(img) + sel(p, lane, U32(0u))), p);
-	}
-	const uint32_t groups = (n - h) >> 4;
-	const uint32_t sh = (h & 3u) * 8u, a0 = img + (h & ~3u);
-	for (uint32_t o = 0; o < groups; o += 64) {
-		const U32 k = U32(o) + lane;
-		const Pred p = k < U32(groups);
-		const U32 a = U32(a0) + sel(p, k, U32(0u)) * 16u;
-		const U32 w0 = lds_ld32(lds, a), w1 = lds_ld32(lds, a + 4u), w2 = lds_ld32(lds, a + 8u), w3 = lds_ld32(lds, a + 12u);
-		U128 v;
-		if (sh) {
-			const U32 w4 = lds_ld32(lds, a + 16u);
-			v.x = (w0 >> U32(sh)) | (w1 << U32(32u - sh));
-			v.y = (w1 >> U32(sh)) | (w2 << U32(32u - sh));
-			v.z = (w2 >> U32(sh)) | (w3 << U32(32u - sh));
-			v.w = (w3 >> U32(sh)) | (w4 << U32(32u - sh));
-		}
-		else {
-			v.x = w0;
-			v.y = w1;
-			v.z = w2;
-			v.w = w3;
-		}
-		gst128(g + h, k * 16u, v, p);
-	}
-	const uint32_t done = h + groups * 16;
-	{
-		Pred p = lane < U32(n - done);
-		gst8(g + done, lane, lds_ld8(lds, U32(img + done) + sel(p, lane, U32(0u))), p);
-	}
-}
-
 // HBM -> HBM copy of n bytes by one wave with 16-byte stores; src may be read up to 31 bytes past src + n
 // (and down to src & ~15), so it is only used on staging buffers that carry that slack.
+// dwords DSEL .. DSEL + 4 of {a, b}, shifted right by sh bits: 16 bytes that start (4 * DSEL + sh / 8) bytes into a
+template <uint32_t DSEL>
+WV_FN U128 funnel128(const U128& a, const U128& b, uint32_t sh)
+{
+	const U32 t0 = DSEL == 0 ? a.x : DSEL == 1 ? a.y : DSEL == 2 ? a.z : a.w;
+	const U32 t1 = DSEL == 0 ? a.y : DSEL == 1 ? a.z : DSEL == 2 ? a.w : b.x;
+	const U32 t2 = DSEL == 0 ? a.z : DSEL == 1 ? a.w : DSEL == 2 ? b.x : b.y;
+	const U32 t3 = DSEL == 0 ? a.w : DSEL == 1 ? b.x : DSEL == 2 ? b.y : b.z;
+	const U32 t4 = DSEL == 0 ? b.x : DSEL == 1 ? b.y : DSEL == 2 ? b.z : b.w;
+	U128 v;
+	if (sh) {
+		v.x = (t0 >> U32(sh)) | (t1 << U32(32u - sh));
+		v.y = (t1 >> U32(sh)) | (t2 << U32(32u - sh));
+		v.z = (t2 >> U32(sh)) | (t3 << U32(32u - sh));
+		v.w = (t3 >> U32(sh)) | (t4 << U32(32u - sh));
+	}
+	else {
+		v.x = t0;
+		v.y = t1;
+		v.z = t2;
+		v.w = t3;
+	}
+	return v;
+}
+// `groups` 16-byte groups to the aligned address d, from the bytes that start smis = 4 * DSEL + sh / 8 bytes behind the
+// aligned address sbase.  Four rounds of 64 groups at a time: all their loads are requested before the first store, so
+// the four rounds cost one memory round trip.
+template <uint32_t DSEL>
+WV_FN void copy_groups(uint8_t* d, const uint8_t* sbase, uint32_t groups, uint32_t sh, bool aligned)
+{
+	const U32 lane = lane_id();
+	for (uint32_t o = 0; o < groups; o += 256) {
+		U128 a0, a1, a2, a3, b0, b1, b2, b3;
+		const U32 k0 = U32(o) + lane, k1 = k0 + 64u, k2 = k0 + 128u, k3 = k0 + 192u;
+		const Pred p0 = k0 < U32(groups), p1 = k1 < U32(groups), p2 = k2 < U32(groups), p3 = k3 < U32(groups);
+		a0 = gld128(sbase, k0 * 16u, p0);
+		a1 = gld128(sbase, k1 * 16u, p1);
+		a2 = gld128(sbase, k2 * 16u, p2);
+		a3 = gld128(sbase, k3 * 16u, p3);
+		if (aligned) {
+			gst128(d, k0 * 16u, a0, p0);
+			gst128(d, k1 * 16u, a1, p1);
+			gst128(d, k2 * 16u, a2, p2);
+			gst128(d, k3 * 16u, a3, p3);
+			continue;
+		}
+		b0 = gld128(sbase, k0 * 16u + 16u, p0);
+		b1 = gld128(sbase, k1 * 16u + 16u, p1);
+		b2 = gld128(sbase, k2 * 16u + 16u, p2);
+		b3 = gld128(sbase, k3 * 16u + 16u, p3);
+		gst128(d, k0 * 16u, funnel128<DSEL>(a0, b0, sh), p0);
+		gst128(d, k1 * 16u, funnel128<DSEL>(a1, b1, sh), p1);
+		gst128(d, k2 * 16u, funnel128<DSEL>(a2, b2, sh), p2);
+		gst128(d, k3 * 16u, funnel128<DSEL>(a3, b3, sh), p3);
+	}
+}
 WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 {
 	const U32 lane = lane_id();
@@ -346,34 +343,12 @@ WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 	const uint32_t groups = (n - h) >> 4;
 	const uint32_t smis = (uint32_t)((uintptr_t)(src + h) & 15u);
 	const uint8_t* sbase = src + h - smis; // 16-byte aligned
-	const uint32_t dsel = smis >> 2, sh = (smis & 3u) * 8u;
-	for (uint32_t o = 0; o < groups; o += 64) {
-		U32 k = U32(o) + lane;
-		Pred p = k < U32(groups);
-		U128 a = gld128(sbase, k * 16u, p);
-		U128 v = a;
-		if (smis) {
-			U128 b = gld128(sbase, k * 16u + 16u, p);
-			// dwords dsel .. dsel + 4 of {a, b}
-			U32 t0 = dsel == 0 ? a.x : dsel == 1 ? a.y : dsel == 2 ? a.z : a.w;
-			U32 t1 = dsel == 0 ? a.y : dsel == 1 ? a.z : dsel == 2 ? a.w : b.x;
-			U32 t2 = dsel == 0 ? a.z : dsel == 1 ? a.w : dsel == 2 ? b.x : b.y;
-			U32 t3 = dsel == 0 ? a.w : dsel == 1 ? b.x : dsel == 2 ? b.y : b.z;
-			U32 t4 = dsel == 0 ? b.x : dsel == 1 ? b.y : dsel == 2 ? b.z : b.w;
-			if (sh) {
-				v.x = (t0 >> U32(sh)) | (t1 << U32(32u - sh));
-				v.y = (t1 >> U32(sh)) | (t2 << U32(32u - sh));
-				v.z = (t2 >> U32(sh)) | (t3 << U32(32u - sh));
-				v.w = (t3 >> U32(sh)) | (t4 << U32(32u - sh));
-			}
-			else {
-				v.x = t0;
-				v.y = t1;
-				v.z = t2;
-				v.w = t3;
-			}
-		}
-		gst128(dst + h, k * 16u, v, p);
+	const uint32_t sh = (smis & 3u) * 8u;
+	switch (smis >> 2) { // which dwords of the two aligned groups make up a destination group: decided once, not per lane
+		case 0: copy_groups<0>(dst + h, sbase, groups, sh, smis == 0); break;
+		case 1: copy_groups<1>(dst + h, sbase, groups, sh, false); break;
+		case 2: copy_groups<2>(dst + h, sbase, groups, sh, false); break;
+		default: copy_groups<3>(dst + h, sbase, groups, sh, false); break;
 	}
 	const uint32_t done = h + groups * 16;
 	{

@@ -166,34 +166,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	if (level >= 1 && g_fused)
 		s_fused = j.nfull / j.bps < s_tight ? j.nfull / j.bps : s_tight;
 	g_last_fused = s_fused;
-	if (s_fused && stream_supported(j.bps, j.T) && g_slots) { // encode_stream: units in LDS images, stored once the superblock's sizes are known
-		const Layout U = make_unit_layout(j.T);
-		const uint32_t ups = stream_units(j.bps, j.T);
-		std::vector<uint8_t*> img(ups);
-		for (uint32_t i = 0; i < ups; ++i)
-			img[i] = alloc_lds(U.total);
-		for (uint64_t s = 0; s < s_fused; ++s) {
-			std::vector<uint32_t> n(ups);
-			uint32_t total = 0;
-			for (uint32_t i = 0; i < ups; ++i) {
-				n[i] = encode_unit(img[i], U, j.T, src + s * sb + (size_t)i * UNIT_BYTES, unit_blocks(j.T));
-				if (n[i] + 48 > unit_image_bytes(j.T))
-					return (size_t)-1;
-				total += n[i];
-			}
-			sboff[s] = carry; // chain_scanner
-			uint32_t prefix = 0;
-			for (uint32_t i = 0; i < ups; ++i) {
-				unit_store(j, img[i], U, s, i, carry, prefix, total, n[i]);
-				prefix += n[i];
-			}
-			carry += 4 + (total > j.sb_bytes ? j.sb_bytes : total);
-		}
-		sboff[s_fused] = total = carry;
-		for (uint32_t i = 0; i < ups; ++i)
-			free(img[i]);
-	}
-	else if (s_fused) {
+	if (s_fused) {
 		const uint32_t run_cap = fused_run_capacity(j.bps, j.T);
 		uint8_t* stage = nullptr;
 		if (posix_memalign((void**)&stage, 64, s_fused * FUSED_WAVES * (size_t)run_cap + 64))

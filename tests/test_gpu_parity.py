@@ -243,16 +243,11 @@ def test_block_pairs_many_seeds(lib, ctx, oracle, T):
         assert r3 == data.nbytes and np.array_equal(back, data), (kind, seed, n)
 
 
-def test_int32_block_loops_agree(lib, ctx, oracle, monkeypatch):
-    """int32 has two block loops in the fused kernel, picked by a probe of the data (kernels.hip, probe_planes): forced
-    either way (STENOS_EXP_INT32_LOOP) they must write the oracle's frame for data of both kinds, and so must the probe."""
+def test_int32_kinds_through_the_fused_kernel(lib, ctx, oracle):
+    """int32 data of every kind goes through the slot encoder of the fused kernel (slot_codec.h): blocks with two
+    non-constant planes in pairs, floats and noise one block per pass; the frames are the oracle's."""
     for kind, n in (("rand12", 700_001), ("sine", 500_003), ("mixed", 600_001), ("lzmix", 400_003), ("rand", 300_001)):
         data = generate(kind, 4, n, 17)
         r1, ref = oracle_compress(oracle, data, 4, 1)
-        for loop in ("slots", "groups", None):
-            if loop is None:
-                monkeypatch.delenv("STENOS_EXP_INT32_LOOP", raising=False)
-            else:
-                monkeypatch.setenv("STENOS_EXP_INT32_LOOP", loop)
-            r2, frame = gpu_compress(lib, ctx, data, 4, 1)
-            assert r1 == r2 and np.array_equal(ref, frame), (kind, loop)
+        r2, frame = gpu_compress(lib, ctx, data, 4, 1)
+        assert r1 == r2 and np.array_equal(ref, frame), kind
