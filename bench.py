@@ -9,9 +9,14 @@ already resident in HBM (device-pointer entry points of libstenos.so; nothing cr
 Workload at N=1: BASELINE.json configs[1], 8 GiB int32 (2^31 elements, bytesoftype 4, level 1 block
 codec only), variant (b) of SURVEY.md section 8d: uniform 12-bit values `u & 0xFFF` from splitmix64 seed 42
 -- the variant in which the codec does real work (ratio ~2.52).  The literal full-entropy variant (a),
-where every superblock falls back to COPY, is measured too and reported under "full_entropy".
+where every superblock falls back to COPY, is measured too and reported under "full_entropy" with a roofline of
+its own.  --config int16 / double run one shard of configs[3] / configs[2] at level 1 the same way.
 With --gpus N every rank owns its own 8 GiB superblock range of an 8*N GiB array (weak scaling, no
-data-path collective).
+data-path collective in the timed region); the gather of the compressed segments to rank 0 and the sharded
+decode are run and timed afterwards ("sharded_exchange").
+Outside the timed region at N=1: the reference's CPU path on a 1 GiB prefix ("cpu_baseline"), a byte-for-byte
+comparison of the GPU frame with the reference's frame of that prefix ("parity_prefix_bytes"), and the host-pointer
+ABI end to end ("host_pointer").
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run.
 Prints ONE JSON line on rank 0.
@@ -36,7 +41,9 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--gib", type=float, default=8.0, help="input GiB per GPU (default: the 8 GiB of configs[1])")
-    p.add_argument("--kind", default="rand12", help="datagen kind for the headline workload")
+    p.add_argument("--config", choices=("int32", "int16", "double"), default="int32", help="BASELINE.json config: int32 = configs[1] (the headline), "
+                   "int16 = one shard of configs[3], double = configs[2] at level 1")
+    p.add_argument("--kind", default=None, help="another datagen kind for the chosen element size (experiments)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-full-entropy", action="store_true", help="skip the extra full-entropy (all COPY) measurement")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
@@ -63,7 +70,7 @@ def cpu_baseline(sample, T, sample_desc):
             ref.stenos_set_threads(ctx, threads)
             best_e = best_d = 1e30
             r = 0
-            for _ in range(3):  # best of N, as benchs/bench_to_csv.cpp:113-126
+            for _ in range(5):  # best of 5, as benchs/bench_to_csv.cpp:113-126
                 t = time.perf_counter()
                 r = ref.stenos_compress_generic(ctx, np_ptr(sample), T, nb, np_ptr(out), out.nbytes)
                 best_e = min(best_e, time.perf_counter() - t)
@@ -142,6 +149,71 @@ def run_workload(st, torch, src, T, steps, warmup, dist, world):
     return dict(wall=wall, enc_s=enc_s, dec_s=dec_s, kenc_ms=kenc / max(steps, 1), kdec_ms=kdec / max(steps, 1), csize=csize, ok=ok)
 
 
+CONFIGS = {
+    # name: (datagen kind, bytesoftype, description)
+    "int32": ("rand12", 4, "configs[1]: {gib:g} GiB int32 per GPU, bytesof=4, level 1, uniform 12-bit values (splitmix64 seed 42, u & 0xFFF)"),
+    "int16": ("walk", 2, "configs[3] shard: {gib:g} GiB int16 random walk per GPU (x += u % 17 - 8, splitmix64 seed 7 + rank), bytesof=2, level 1"),
+    "double": ("sine", 8, "configs[2] at level 1: {gib:g} GiB double sin(i * 0.001) per GPU, bytesof=8"),
+}
+
+
+def roofline(kernel, algo_bytes, kernel_ms, traffic=None, traffic_source=None):
+    achieved = algo_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kernel_ms, 4)}
+
+
+def reference_prefix_parity(st, torch, src, T, nprefix):
+    """Byte-for-byte check at benchmark scale, outside the timed region: the reference's frame of the first `nprefix` bytes
+    of the workload (whole superblocks) against the same superblocks of the GPU's frame of the whole array -- superblocks
+    are coded independently, so the streams must be identical.  Returns the compared frame bytes or None."""
+    import numpy as np
+
+    from _libs import load_ref, np_ptr
+
+    ref = load_ref(det=False)
+    if ref is None:
+        return None
+    sample = src[:nprefix].cpu().numpy()
+    exp = np.zeros(ref.stenos_bound(nprefix), dtype=np.uint8)
+    ctx = ref.stenos_make_context()
+    ref.stenos_set_level(ctx, 1)
+    ref.stenos_set_threads(ctx, os.cpu_count() or 1)
+    r = ref.stenos_compress_generic(ctx, np_ptr(sample), T, nprefix, np_ptr(exp), exp.nbytes)
+    ref.stenos_destroy_context(ctx)
+    dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device=src.device)
+    st.compress(src, T, dst)
+    got = dst[8:r].cpu().numpy()
+    assert np.array_equal(got, exp[8:r]), "GPU frame differs from the reference's frame on the common superblocks"
+    return int(r - 8)
+
+
+def host_pointer_rate(T, sample):
+    """The frozen ABI with host pointers (stenos_compress_generic / stenos_decompress_generic): PCIe both ways included."""
+    import numpy as np
+
+    from _libs import np_ptr
+    from stenos_amd.api import load_library
+
+    lib = load_library()
+    ctx = lib.stenos_make_context()
+    nb = sample.nbytes
+    out = np.zeros(lib.stenos_bound(nb), dtype=np.uint8)
+    back = np.zeros(nb, dtype=np.uint8)
+    best_e = best_d = 1e30
+    for _ in range(3):
+        t = time.perf_counter()
+        r = lib.stenos_compress_generic(ctx, np_ptr(sample), T, nb, np_ptr(out), out.nbytes)
+        best_e = min(best_e, time.perf_counter() - t)
+        t = time.perf_counter()
+        d = lib.stenos_decompress_generic(ctx, np_ptr(out), T, r, np_ptr(back), nb)
+        best_d = min(best_d, time.perf_counter() - t)
+        assert d == nb
+    lib.stenos_destroy_context(ctx)
+    return {"encode_gbps": round(nb / best_e / 1e9, 2), "decode_gbps": round(nb / best_d / 1e9, 2), "sample_bytes": nb,
+            "note": "host pointers through the C ABI, pageable memory, PCIe both ways included; never the headline value"}
+
+
 def main():
     args = parse()
     import torch
@@ -153,7 +225,7 @@ def main():
     import torch.distributed as dist
 
     # one process per GPU; STENOS_BENCH_ONE_DEVICE=1 (test rigs with a single GPU) puts every rank on cuda:0
-    # and uses gloo for the barrier / max reduction, which are the only collectives of this benchmark
+    # and uses gloo for the collectives (two ranks cannot share a GPU under RCCL)
     one_device = os.environ.get("STENOS_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local = 0
@@ -165,13 +237,19 @@ def main():
     from stenos_amd.api import Stenos
     from stenos_amd.datagen import generate_torch
 
-    T = 4
+    kind, T, desc = CONFIGS[args.config]
+    if args.kind:
+        kind, desc = args.kind, "{gib:g} GiB per GPU, bytesof=%d, kind=%s" % (T, args.kind)
     n = int(args.gib * (1 << 30)) // T
     nbytes = n * T
+    dev = f"cuda:{local}"
     st = Stenos(level=1)
     st.set_profiling(True)
 
-    src = generate_torch(args.kind, T, n, seed=42, device=f"cuda:{local}", start=rank * n)
+    if kind == "walk":  # a series of its own per shard
+        src = generate_torch(kind, T, n, seed=7 + rank, device=dev)
+    else:
+        src = generate_torch(kind, T, n, seed=42, device=dev, start=rank * n)
     torch.cuda.synchronize()
     r = run_workload(st, torch, src, T, args.steps, args.warmup, dist, world)
     assert r["ok"], "round trip mismatch"
@@ -183,17 +261,21 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (encode_superblocks, the fused encoder): algorithmic bytes = N read + C written per launch
         algo = nbytes + r["csize"]
-        achieved = algo / (r["kenc_ms"] / 1e3) / 1e9 if r["kenc_ms"] > 0 else 0.0
-        traffic = None
+        traffic = source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if args.config == "int32" and not args.kind and args.gib == 8.0 and os.path.exists(pmc):
+            # counters cannot be collected inside this run: the figure is the one of the committed profile, with its origin
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("encode_superblocks_hbm_bytes_per_launch")
+                    j = json.load(f)
+                traffic = j.get("encode_superblocks_hbm_bytes_per_launch")
+                source = f"profiles/pmc_traffic.json ({j.get('profile', '?')}, build {j.get('build', '?')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload, separate passes"
             except Exception:
-                traffic = None
+                traffic = source = None
+        roof = roofline("encode_superblocks", algo, r["kenc_ms"], traffic, source)
+        roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"]).items() if k in ("achieved", "frac", "kernel_ms")}
         out = {
-            "metric": "encode+decode GB/s (input bytes) at level 1, int32",
+            "metric": "encode+decode GB/s (input bytes) at level 1, int32" if T == 4 else f"encode+decode GB/s (input bytes) at level 1, bytesof={T}",
             "value": round(value, 3),
             "unit": "GB/s",
             "n_gpus": world,
@@ -205,33 +287,78 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.gib:g} GiB int32 per GPU, bytesof=4, level 1, uniform 12-bit values (splitmix64 seed 42, u & 0xFFF)"
-                       if args.kind == "rand12" else f"{args.gib:g} GiB int32 per GPU, kind={args.kind}",
-                       "bytesoftype": T, "level": 1, "superblock_bytes": 131072, "sharding": f"{world} x contiguous superblock ranges"},
+            "config": {"workload": desc.format(gib=args.gib), "bytesoftype": T, "level": 1, "superblock_bytes": 131072 // (256 * T) * 256 * T,
+                       "sharding": f"{world} x contiguous superblock ranges"},
             "compression_ratio": round(ratio, 4),
             "encode_gbps": round(nbytes * args.steps / r["enc_s"] / 1e9, 3),
             "decode_gbps": round(nbytes * args.steps / r["dec_s"] / 1e9, 3),
-            "roofline": {"bound": "hbm", "kernel": "encode_superblocks", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo, "kernel_ms": round(r["kenc_ms"], 4),
-                         "decode_superblocks": {"achieved": round(algo / (r["kdec_ms"] / 1e3) / 1e9, 2) if r["kdec_ms"] > 0 else 0.0,
-                                                "kernel_ms": round(r["kdec_ms"], 4)}},
+            "roofline": roof,
         }
-    # the literal "random int32" variant: every superblock becomes COPY (reported, not the headline)
-    if world == 1 and not args.no_full_entropy:
-        src2 = generate_torch("rand", T, n, seed=42, device=f"cuda:{local}")
-        r2 = run_workload(st, torch, src2, T, max(1, min(3, args.steps)), 1, dist, world)
-        assert r2["ok"]
+    # the literal "random int32" variant: every superblock becomes COPY (reported next to the headline, with its own roofline)
+    if world == 1 and T == 4 and not args.kind and not args.no_full_entropy:
+        src2 = generate_torch("rand", T, n, seed=42, device=dev)
         k = max(1, min(3, args.steps))
-        out["full_entropy"] = {"value": round(nbytes * k / r2["wall"] / 1e9, 3), "compression_ratio": round(nbytes / r2["csize"], 5),
-                               "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3)}
+        r2 = run_workload(st, torch, src2, T, k, 1, dist, world)
+        assert r2["ok"]
+        algo2 = nbytes + r2["csize"]
+        roof2 = roofline("encode_superblocks", algo2, r2["kenc_ms"])
+        roof2["decode_superblocks"] = {kk: v for kk, v in roofline("decode_superblocks", algo2, r2["kdec_ms"]).items() if kk in ("achieved", "frac", "kernel_ms")}
+        out["full_entropy"] = {"workload": "the literal configs[1]: uniform 32-bit values (splitmix64 seed 42), every superblock stored as a copy",
+                               "value": round(nbytes * k / r2["wall"] / 1e9, 3), "compression_ratio": round(nbytes / r2["csize"], 5),
+                               "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3), "roofline": roof2}
         del src2
-    if world == 1:
-        if not args.no_cpu_baseline:
-            mib = min(args.cpu_sample_mib, nbytes >> 20)
-            sample_bytes = (mib << 20) + 4000 if (mib << 20) + 4000 <= nbytes else nbytes  # not a superblock multiple: the reference decoder rejects those
-            sample = src[:sample_bytes].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(sample, T, f"first {mib} MiB + 4000 B of the same workload, best of 3")
+    if world == 1 and not args.no_cpu_baseline:
+        mib = min(args.cpu_sample_mib, nbytes >> 20)
+        sample_bytes = (mib << 20) + 4000 if (mib << 20) + 4000 <= nbytes else nbytes  # not a superblock multiple: the reference decoder rejects those
+        sample = src[:sample_bytes].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(sample, T, f"first {mib} MiB + 4000 B of the same workload, best of 5")
+        out["parity_prefix_bytes"] = reference_prefix_parity(st, torch, src, T, mib << 20)
+        out["host_pointer"] = host_pointer_rate(T, sample)
+        del sample
+    if world > 1:
+        # The one exchange of the sharded form, after the timed region and timed on its own: the compressed segments go to
+        # rank 0 (RCCL over xGMI with the nccl backend), rank 0 cuts the assembled frame again and every rank decodes its
+        # segment; each rank checks its slice against its input.
+        from stenos_amd.sharded import decompress_sharded, gather_frames
+
+        extra = {}
+        try:
+            dst = torch.empty(st.bound(nbytes), dtype=torch.uint8, device=dev)
+            csize = st.compress(src, T, dst)
+            local = dst[:csize]
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            frame = gather_frames(local, world * nbytes)
+            torch.cuda.synchronize()
+            dist.barrier()
+            gather_s = time.perf_counter() - t0
+            sizes = torch.tensor([float(csize)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(sizes)
+            moved = float(sizes.item()) - csize if rank == 0 else 0.0
+            index = st.frame_index(frame, T, frame.numel()) if rank == 0 else None
+            back = torch.empty_like(src)
+
+            def decode(seg, nb):
+                st.decompress(seg, T, seg.numel(), back[:nb])
+                return back[:nb]
+
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            part, o0, o1 = decompress_sharded(decode, frame, index, world * nbytes, T, dev)
+            torch.cuda.synchronize()
+            dist.barrier()
+            scatter_decode_s = time.perf_counter() - t0
+            ok = torch.tensor([1.0 if (o1 - o0 == nbytes and o0 == rank * nbytes and torch.equal(part, src)) else 0.0], dtype=torch.float64,
+                              device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            extra = {"gather_ms": round(gather_s * 1e3, 3), "gather_bytes_to_rank0": int(moved), "gather_gbps": round(moved / gather_s / 1e9, 2) if gather_s > 0 else None,
+                     "scatter_decode_ms": round(scatter_decode_s * 1e3, 3), "sharded_roundtrip_ok": bool(ok.item() == 1.0), "backend": dist.get_backend()}
+        except Exception as e:  # the headline line must not be lost to the exchange
+            extra = {"gather_error": repr(e)[:300]}
+        if rank == 0:
+            out["sharded_exchange"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)
     st.close()

@@ -35,6 +35,12 @@ STENOS_EXPORT size_t stenos_hip_finish(stenos_context* ctx);
  * superblock headers inside the frame (the last entry is the frame size).  Valid until the next call on ctx. */
 STENOS_EXPORT const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb);
 
+/* Superblock index of any frame held in device memory: the chain of [code][csize:3] headers (reference
+ * stenos.cpp:1126-1134, 1166-1182) is walked on the device.  Returns a device array of *nsb + 1 uint64 byte offsets
+ * (the last entry is the end of the last superblock), valid until the next call on ctx; NULL for an empty,
+ * malformed or truncated frame.  Waits for the walk.  What a multi-GPU decoder cuts the frame with. */
+STENOS_EXPORT const uint64_t* stenos_hip_frame_index(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, size_t* nsb, void* stream);
+
 /* Decompress a frame held in device memory.  d_index may be NULL: the superblock chain
  * ([code][csize:3] headers, reference stenos.cpp:1129-1134) is then walked on the device first
  * (serial, latency bound); passing the index produced by stenos_hip_last_index() skips that walk.
@@ -52,9 +58,9 @@ STENOS_EXPORT size_t stenos_hip_delta(const void* d_src, void* d_dst, size_t byt
 STENOS_EXPORT size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t bytes, void* stream);
 
 /* Kernel timing for benchmarks: when enabled, HIP events are recorded on the job's stream around the
- * dominant kernel of each direction (encode_blocks, decode_superblocks).  stenos_hip_kernel_ms returns the
- * elapsed milliseconds of the last such launch (which: 0 = encode_blocks, 1 = decode_superblocks), or a
- * negative value when none was recorded; it waits for the end event. */
+ * dominant kernel of each direction: which = 0, the encoder (encode_superblocks, the fused kernel; encode_blocks
+ * where that one does not apply), which = 1, decode_superblocks.  stenos_hip_kernel_ms returns the elapsed
+ * milliseconds of the last such launch, or a negative value when none was recorded; it waits for the end event. */
 STENOS_EXPORT void stenos_hip_set_profiling(stenos_context* ctx, int enabled);
 STENOS_EXPORT double stenos_hip_kernel_ms(stenos_context* ctx, int which);
 

@@ -79,6 +79,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "stenos_hip_compress_async": (sz, [vp, vp, sz, sz, vp, sz, vp]),
         "stenos_hip_finish": (sz, [vp]),
         "stenos_hip_last_index": (vp, [vp, ctypes.POINTER(sz)]),
+        "stenos_hip_frame_index": (vp, [vp, vp, sz, sz, ctypes.POINTER(sz), vp]),
         "stenos_hip_decompress": (sz, [vp, vp, sz, sz, vp, sz, vp, vp]),
         "stenos_hip_decompress_async": (sz, [vp, vp, sz, sz, vp, sz, vp, vp]),
         "stenos_hip_shuffle": (sz, [vp, sz, sz, vp, vp]),
@@ -151,6 +152,21 @@ class Stenos:
         n = c_size_t(0)
         p = self.lib.stenos_hip_last_index(self.ctx, ctypes.byref(n))
         return p, n.value
+
+    def frame_index(self, frame, bytesoftype: int, csize: int):
+        """Offsets of the superblock headers of any frame on the device (nsb + 1 of them, the last one is the end) as a
+        list of ints; raises for a malformed or truncated frame."""
+        import torch
+
+        n = c_size_t(0)
+        p = self.lib.stenos_hip_frame_index(self.ctx, frame.data_ptr(), bytesoftype, csize, ctypes.byref(n), self._stream_ptr())
+        if not p:
+            raise StenosError((1 << 64) - 4)
+        host = torch.empty(n.value + 1, dtype=torch.int64)
+        hip = ctypes.CDLL("libamdhip64.so")
+        if hip.hipMemcpy(c_void_p(host.data_ptr()), c_void_p(p), c_size_t((n.value + 1) * 8), 2) != 0:
+            raise StenosError((1 << 64) - 1)
+        return host.tolist()
 
     def decompress(self, frame, bytesoftype: int, csize: int, dst, index_ptr: int | None = None, wait: bool = True) -> int:
         fn = self.lib.stenos_hip_decompress if wait else self.lib.stenos_hip_decompress_async

@@ -874,7 +874,7 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 	ctx->job_kind = 0;
 	if (bytes && needs_strategy(T, level)) {
 		// the strategy layer needs the input on the host (estimator, zstd): fetch it, assemble the frame there
-		const size_t roomy = stenos_bound(bytes) + f.sb / 128 + 4096; // beyond ZSTD_compressBound of a superblock the capacity no longer matters
+		const size_t roomy = f.header + f.nsb * 4 + bytes + f.sb / 128 + 4096; // beyond the largest frame (all copies) + ZSTD_compressBound's margin the capacity no longer matters
 		const size_t cap = dst_size < roomy ? dst_size : roomy;
 		HostBuf &h_src = ctx->h_in, &h_out = ctx->h_out;
 		if (!h_src.ensure(bytes + 64) || !h_out.ensure(cap + 64))
@@ -944,7 +944,9 @@ size_t parse_frame(const uint8_t* h, size_t have, size_t T, size_t dst_size, Fra
 			return STENOS_ERROR_SRC_OVERFLOW;
 		fi.sb = (size_t)get_le(h + 8, 4);
 		fi.header = 12;
-		if (fi.sb == 0)
+		// what the compressor can have written (prepare(): a whole number of blocks' worth, below STENOS_MAX_BLOCK_BYTES);
+		// the reference trusts the field (stenos.cpp:1098-1103) and would divide by zero or size buffers from garbage
+		if (fi.sb < T * 256 || fi.sb >= STENOS_MAX_BLOCK_BYTES)
 			return STENOS_ERROR_INVALID_INPUT;
 	}
 	else
@@ -952,6 +954,8 @@ size_t parse_frame(const uint8_t* h, size_t have, size_t T, size_t dst_size, Fra
 	// Unlike the reference (stenos.cpp:1115-1116, 1131) the last superblock of a frame whose size is an
 	// exact multiple of the superblock size is decoded with its full size instead of 0 bytes.
 	fi.nsb = fi.total / fi.sb + (fi.total % fi.sb ? 1 : 0);
+	if (fi.nsb > 0x7FFFFFFFull) // one workgroup per superblock: beyond the grid limit (256 TiB of int32)
+		return STENOS_ERROR_INVALID_PARAMETER;
 	return 0;
 }
 
@@ -1109,7 +1113,8 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 		return 0;
 	if (T > kMaxT)
 		return STENOS_ERROR_INVALID_PARAMETER;
-	if (!ctx->misc.ensure(4096) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
+	// (a caller's index may be the context's own, from stenos_hip_last_index / stenos_hip_frame_index: only touch it when none is given)
+	if (!ctx->misc.ensure(4096) || (!d_index && !ctx->sboff.ensure((fi.nsb + 2) * 8)))
 		return STENOS_ERROR_ALLOC;
 	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
 	if (hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess)
@@ -1246,15 +1251,16 @@ size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t byte
 	}
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
-	const size_t bound = stenos_bound(bytes);
-	if (!ctx->in.ensure(bytes + 64) || !ctx->out.ensure(bound + 64))
+	// the largest frame there can be: every superblock stored as a copy.  (stenos_bound() assumes superblocks of the
+	// default size; with stenos_set_block_size() there can be many more headers.)  Nothing is written past dst_size.
+	const size_t worst = f.header + f.nsb * 4 + bytes;
+	if (!ctx->in.ensure(bytes + 64) || !ctx->out.ensure((dst_size < worst ? dst_size : worst) + 64))
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	if (needs_strategy(bytesoftype, ctx->level))
 		return compress_strategy(ctx, (const uint8_t*)src, ctx->in.as<uint8_t>(), bytesoftype, bytes, out, dst_size, ctx->level, f, nullptr);
-	// the device buffer holds `bound` bytes, which every frame fits; the caller's dst_size is the logical
-	// capacity (a frame that does not fit is reported, nothing is written past dst_size)
+	// the caller's dst_size is the logical capacity (a frame that does not fit is reported, nothing is written past it)
 	size_t r = compress_device(ctx, ctx->in.p, bytesoftype, bytes, ctx->out.p, dst_size, nullptr, true);
 	if (is_err(r))
 		return r;
@@ -1339,16 +1345,25 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	return (size_t)fi.total;
 }
 
+// The reference builds a temporary context per call (stenos.cpp:1210-1226).  Here a context owns device buffers of about
+// twice the input, so the one-shot calls of a thread share one context that lives as long as the thread: its buffers
+// are kept between calls (and freed by the thread's exit).
+static stenos_context_s& one_shot_context()
+{
+	static thread_local stenos_context_s ctx;
+	ctx.max_nanoseconds = 0;
+	ctx.custom_shift = STENOS_NO_BLOCK_SHIFT;
+	return ctx;
+}
 size_t stenos_compress(const void* src, size_t bytesoftype, size_t bytes, void* dst, size_t dst_size, int level)
 {
-	stenos_context_s ctx; // temporary context (stenos.cpp:1210-1218)
+	stenos_context_s& ctx = one_shot_context();
 	ctx.level = level > 9 ? 9 : (level < 0 ? 0 : level);
 	return stenos_compress_generic(&ctx, src, bytesoftype, bytes, dst, dst_size);
 }
 size_t stenos_decompress(const void* src, size_t bytesoftype, size_t bytes, void* dst, size_t dst_size)
 {
-	stenos_context_s ctx;
-	return stenos_decompress_generic(&ctx, src, bytesoftype, bytes, dst, dst_size);
+	return stenos_decompress_generic(&one_shot_context(), src, bytesoftype, bytes, dst, dst_size);
 }
 
 size_t stenos_get_info(const void* src, size_t bytesoftype, size_t bytes, stenos_info* info) // stenos.cpp:1019-1050
@@ -1639,6 +1654,33 @@ const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb)
 {
 	if (nsb)
 		*nsb = ctx->last_nsb;
+	return ctx->sboff.as<uint64_t>();
+}
+
+const uint64_t* stenos_hip_frame_index(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, size_t* nsb, void* stream_)
+{
+	if (nsb)
+		*nsb = 0;
+	hipStream_t stream = (hipStream_t)stream_;
+	if (!ctx || !d_src || !ctx->device_ready())
+		return nullptr;
+	uint8_t h[12] = { 0 };
+	const size_t have = bytes < 12 ? bytes : 12;
+	if (have && (hipMemcpyAsync(h, d_src, have, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
+		return nullptr;
+	FrameInfo fi;
+	if (is_err(parse_frame(h, have, bytesoftype, ~(size_t)0, fi)) || fi.total == 0)
+		return nullptr;
+	if (!ctx->misc.ensure(4096) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
+		return nullptr;
+	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
+	uint32_t status = 0;
+	if (hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess ||
+	    stenos_k_launch_walk((const uint8_t*)d_src, bytes, fi.header, fi.nsb, ctx->sboff.as<uint64_t>(), d_status, stream) != hipSuccess ||
+	    hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || status)
+		return nullptr; // a header or payload runs past the end of the frame
+	if (nsb)
+		*nsb = (size_t)fi.nsb;
 	return ctx->sboff.as<uint64_t>();
 }
 

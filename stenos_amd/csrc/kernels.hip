@@ -185,6 +185,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 	fused_run_range(j.bps, w, &b0, &b1);
 	uint64_t prev = CHAIN_FAILED; // superblock that is encoded but not stored yet
 	uint32_t prev_run[FUSED_WAVES];
+	bool guess_copy = false; // the workgroup's last superblock ended up as a copy
 	if (threadIdx.x == 0)
 		shared[2] = 0;
 	for (uint32_t it = 0; FUSED_TICKETS == 0 || it <= FUSED_TICKETS; ++it) {
@@ -198,22 +199,35 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 		const uint64_t s = (uint32_t)__builtin_amdgcn_readfirstlane(shared[parity]);
 		const bool work = s < nsb;
 		volatile uint32_t* runs = shared + 8 + 4 * parity;
-		if (work) {
-			const uint32_t n = encode_run(g_lds + w * L.total, L, T, j.src + (s * j.bps + b0) * (uint64_t)(256 * T), b1 - b0,
-						      stage_w + (uint64_t)parity * FUSED_WAVES * run_cap);
-			if ((threadIdx.x & 63u) == 0)
-				runs[w] = n;
-		}
-		__syncthreads();
 		uint32_t run_size[FUSED_WAVES];
 		if (work) {
-			for (uint32_t k = 0; k < FUSED_WAVES; ++k)
-				run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(runs[k]);
-			uint32_t code;
-			const uint32_t bytes = fused_superblock_size(j, run_size, &code);
-			if (threadIdx.x == 0)
-				chain_put(size + s, bytes);
+			// A superblock whose block stream comes out larger than its input is stored as a copy (stenos.cpp:609-610) and
+			// the stream is thrown away: after such a superblock the next one is only measured (nothing written, nothing
+			// staged) and encoded for real only if the guess was wrong.  Incompressible data is incompressible throughout.
+			const uint8_t* from = j.src + (s * j.bps + b0) * (uint64_t)(256 * T);
+			uint8_t* to = stage_w + (uint64_t)parity * FUSED_WAVES * run_cap;
+			for (uint32_t attempt = 0;; ++attempt) {
+				const bool measure = guess_copy && attempt == 0;
+				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to);
+				if ((threadIdx.x & 63u) == 0)
+					runs[w] = n;
+				__syncthreads();
+				for (uint32_t k = 0; k < FUSED_WAVES; ++k)
+					run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(runs[k]);
+				uint32_t code;
+				const uint32_t bytes = fused_superblock_size(j, run_size, &code);
+				if (measure && code != 6) { // it does compress: once more, with the bytes
+					__syncthreads(); // (everyone has read the sizes before they are written again)
+					continue;
+				}
+				guess_copy = code == 6;
+				if (threadIdx.x == 0)
+					chain_put(size + s, bytes);
+				break;
+			}
 		}
+		else
+			__syncthreads();
 		if (prev != CHAIN_FAILED) {
 			const uint64_t off = chain_wait(j, prev);
 			if (off == CHAIN_FAILED)
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 	const uint64_t s = a.sb_ids ? a.sb_ids[blockIdx.x] : blockIdx.x;
 	const U32 lane = lane_id();
 	const uint64_t p = a.sb_off[blockIdx.x];
-	if (p + 4 > a.size) {
+	if (p > a.size || a.size - p < 4) { // (written without sums: an index entry may hold anything)
 		if (threadIdx.x == 0)
 			atomicOr(a.status, DECODE_STATUS_TRUNCATED);
 		return;
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 	const uint32_t csize = (uint32_t)a.frame[p + 1] | ((uint32_t)a.frame[p + 2] << 8) | ((uint32_t)a.frame[p + 3] << 16);
 	const uint64_t begin = s * (uint64_t)a.sb_bytes;
 	const uint32_t dsize = (uint32_t)((a.total_bytes - begin) < a.sb_bytes ? (a.total_bytes - begin) : a.sb_bytes);
-	if (p + 4 + csize > a.size) { // stenos.cpp:1133-1134
+	if (a.size - p - 4 < csize) { // stenos.cpp:1133-1134
 		if (threadIdx.x == 0)
 			atomicOr(a.status, DECODE_STATUS_TRUNCATED);
 		return;
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 				atomicOr(a.status, DECODE_STATUS_INVALID);
 			return;
 		}
-		copy_g2g(out, payload, csize);
+		copy_g2g_wide(out, payload, csize);
 	}
 	else if (code >= 2 && code <= 5) { // zstd based codes are finished by the host
 		if (threadIdx.x == 0)

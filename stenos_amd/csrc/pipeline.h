@@ -294,7 +294,7 @@ WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, 
 		uint32_t b0, b1;
 		fused_run_range(j.bps, w, &b0, &b1);
 		const uint32_t bs = 256 * j.T;
-		copy_g2g(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
+		copy_g2g_wide(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
 	}
 }
 
@@ -355,7 +355,7 @@ WV_FN void pack_superblock(Lds lds, const FrameJob& j, uint64_t s, uint32_t w)
 		// one contiguous source: the host-prepared payload, or the raw input bytes of a COPY superblock
 		const uint8_t* srcp = (j.tiny_last && s == j.nsb - 1) ? j.override_payload : j.src + first * (uint64_t)(256 * j.T);
 		const uint32_t b0 = d0 * 4 > mis ? d0 * 4 - mis : 0, b1 = d1 * 4 - mis < csize ? d1 * 4 - mis : csize;
-		copy_g2g(pay + b0, srcp + b0, b1 - b0);
+		copy_g2g_wide(pay + b0, srcp + b0, b1 - b0);
 		return;
 	}
 	(void)has_tail;

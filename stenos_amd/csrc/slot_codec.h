@@ -80,11 +80,13 @@ WV_FN void write_slots_fast(Lds lds, const Layout& L, const RawBlock& b, uint32_
 	}
 }
 
-// Distinct hash keys among the first 80 values of a block of bytesoftype 4 that is still in registers (lanes 0..19
-// hold them): the first rejection test of the mini-LZ (block_codec.h, lz_precheck_passes).  hash_val
-// (lz_compress.h:47-56) keeps the low byte of value * 2654435761, which only depends on the value's low byte.  Every
-// value writes a tag of its own into table[key]; after all writes each key holds exactly one tag, so the values that
-// find their own tag back are as many as there are distinct keys.  No zeroing, no atomics.
+// Distinct hash keys among the first 20 * ROUNDS values of a block of bytesoftype 4 that is still in registers (lanes
+// 0..19 hold the first 80, value k of a lane in round k): the first rejection test of the mini-LZ (block_codec.h,
+// lz_precheck_passes) wants the count over all 80; the count over the first 40 is a lower bound of it that is enough to
+// turn most blocks away.  hash_val (lz_compress.h:47-56) keeps the low byte of value * 2654435761, which only depends on
+// the value's low byte.  Every value writes a tag of its own into table[key]; after all writes each key holds exactly one
+// tag, so the values that find their own tag back are as many as there are distinct keys.  No zeroing, no atomics.
+template <int ROUNDS>
 WV_FN uint32_t lz_distinct_keys_fast(Lds lds, const Layout& L, const U128& e)
 {
 	uint32_t distinct = 0;
@@ -92,16 +94,39 @@ WV_FN uint32_t lz_distinct_keys_fast(Lds lds, const Layout& L, const U128& e)
 		const U32 lane = lane_id();
 		const U32 v[4] = { e.x, e.y, e.z, e.w };
 		U32 addr[4];
-		for (int k = 0; k < 4; ++k) {
+		for (int k = 0; k < ROUNDS; ++k) {
 			addr[k] = U32(L.tab) + (mul24(v[k], U32(0xB1u * 4u)) & 0x3FCu);
 			lds_st32(lds, addr[k], lane + U32(64u * (uint32_t)k), in);
 		}
 		wave_sync();
-		for (int k = 0; k < 4; ++k)
+		for (int k = 0; k < ROUNDS; ++k)
 			distinct += (uint32_t)__builtin_popcountll(ballot(in & (lds_ld32(lds, addr[k]) == lane + U32(64u * (uint32_t)k))));
 	});
 	wave_sync();
 	return first_lane_value(distinct); // the other lanes have not counted
+}
+
+// Second rejection test of the mini-LZ for a block of bytesoftype 4 in registers (block_codec.h, lz_try): a value can only
+// match when an equal value precedes it, and equal values have equal hashes.  One bit per 13-bit hash value (1 KiB at
+// L.tab) counts the values whose hash has been seen before; if even with all of them matching the stream exceeds
+// max_size, the reference fails after doing all the work (lz_compress.h:221-223).  True: the attempt is pointless.
+WV_FN bool lz_repeats_reject(Lds lds, const Layout& L, const U128& e, uint32_t max_size)
+{
+	const U32 lane = lane_id();
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	lds_st128(lds, U32(L.tab) + lane * 16u, z, pred_all(true));
+	wave_sync();
+	const U32 v[4] = { e.x, e.y, e.z, e.w };
+	uint32_t maybe = 0;
+	for (int k = 0; k < 4; ++k) {
+		const U32 h = (v[k] * 0x85EBCA6Bu) >> 19;
+		const U32 bit = U32(1u) << (h & 31u);
+		const U32 old = lds_or_rtn32(lds, U32(L.tab) + (h >> 5) * 4u, bit);
+		maybe += (uint32_t)__builtin_popcountll(ballot((old & bit) != U32(0u)));
+	}
+	wave_sync();
+	return 256 / 8 + 256 * 4 - maybe * 3 > max_size;
 }
 
 // ---- row lanes ---------------------------------------------------------------------------------------------------------

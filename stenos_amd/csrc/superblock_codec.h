@@ -62,40 +62,6 @@ WV_FN void store_block(uint8_t* g, Lds lds, uint32_t ldsoff, uint32_t n)
 		}
 }
 
-// HBM -> HBM copy of n bytes by one wave; any alignment on both sides.  Source words are read from
-// the 4-byte aligned addresses that contain the bytes (never below src & ~3, never at or past the
-// aligned word that holds the last byte + 1), destination words are written aligned.
-WV_FN void copy_g2g(uint8_t* dst, const uint8_t* src, uint32_t n)
-{
-	const U32 lane = lane_id();
-	const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u); // bytes until dst is 4-byte aligned
-	const uint32_t h = head < n ? head : n;
-	{
-		Pred p = lane < U32(h);
-		gst8(dst, lane, gld8(src, lane, p), p);
-	}
-	const uint32_t words = (n - h) >> 2;
-	const uint32_t smis = (uint32_t)((uintptr_t)(src + h) & 3u);
-	const uint8_t* sbase = src + h - smis; // 4-byte aligned
-	const uint32_t sh = smis * 8u;
-	for (uint32_t o = 0; o < words; o += 64) {
-		U32 k = U32(o) + lane;
-		Pred p = k < U32(words);
-		U32 lo = gld32(sbase, k * 4u, p);
-		U32 v = lo;
-		if (sh) { // the upper word still holds at least one byte of [src, src + n)
-			U32 hi = gld32(sbase, k * 4u + 4u, p);
-			v = (lo >> U32(sh)) | (hi << U32(32u - sh));
-		}
-		gst32(dst + h, k * 4u, v, p);
-	}
-	const uint32_t done = h + words * 4;
-	{
-		Pred p = lane < U32(n - done);
-		gst8(dst + done, lane, gld8(src + done, lane, p), p);
-	}
-}
-
 // ---- encode side -----------------------------------------------------------------------------------
 
 // One full block: HBM -> LDS -> encoded image -> 16-byte aligned slot.
@@ -152,9 +118,16 @@ WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 // that image it starts at (base, < 16) and takes the bytes over once they are written (append).
 struct StreamSink { // a contiguous stream in HBM (RunStream)
 	RunStream rs;
+	bool writes; // false: sizes only, nothing is written (a superblock that is expected to end up as a copy, kernels.hip)
 	WV_MFN Layout at(const Layout& L) const { return L; }
 	WV_MFN uint32_t base() const { return rs.pos & 15u; }
-	WV_MFN void append(Lds lds, const Layout& L, uint32_t n) { stream_append(rs, lds, L.out, n); }
+	WV_MFN void append(Lds lds, const Layout& L, uint32_t n)
+	{
+		if (writes)
+			stream_append(rs, lds, L.out, n);
+		else
+			rs.pos += n;
+	}
 };
 
 // `nblocks` full blocks at src -> their encodings, back to back, into the sink.  Ample capacity is assumed (the
@@ -187,7 +160,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				WV_MARK("block_begin");
 				const Layout M = sink.at(L);
 				SlotBatch B;
-				uint32_t keys0 = 0, keys1 = 0; // distinct hash keys at the head of each block (first rejection test of the mini-LZ)
+				uint32_t keys0 = 0, keys1 = 0; // distinct hash keys among the first 40 values of each block (first rejection test of the mini-LZ)
 				{
 					const SameScan sa = scan_same_fast(ea, T);
 					B.act[0] = sa.act;
@@ -205,9 +178,9 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					}
 				}
 								if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
-					keys0 = lz_distinct_keys_fast(lds, M, ea.e);
+					keys0 = lz_distinct_keys_fast<2>(lds, M, ea.e);
 				if (T == 4 && nblk > 1 && B.nslots - B.nact0 >= 2)
-					keys1 = lz_distinct_keys_fast(lds, M, eb.e);
+					keys1 = lz_distinct_keys_fast<2>(lds, M, eb.e);
 				write_slots_fast(lds, M, ea, T, B.act[0], 0);
 				if (nblk > 1)
 					write_slots_fast(lds, M, eb, T, B.act[1], B.nact0);
@@ -224,17 +197,28 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 				WV_MARK("plane_offsets");
 				const SlotPlace P = slot_rows_place(R, B, T);
-				if (T == 4) { // those that pass the first rejection test (most do not)
-					if (B.full[0] * 3 > bs && lz_precheck_passes(T, keys0, B.full[0]))
-						lzq |= 1u;
-					if (nblk > 1 && B.full[1] * 3 > bs && lz_precheck_passes(T, keys1, B.full[1]))
-						lzq |= 2u;
+				if (T == 4) {
+					// Those that pass the first two rejection tests (most fail the first, noise the second).  The key counts
+					// cover the first 40 values; only a block they do not turn away is looked at again.
+					// (constant indices: a loop over the blocks would send the batch's scalars through memory)
+					if (B.full[0] * 3 > bs && lz_precheck_passes(T, keys0, B.full[0])) {
+						const RawBlock e = load_raw_block(a, T);
+						if (lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[0]) && !lz_repeats_reject(lds, M, e.e, B.full[0]))
+							lzq |= 1u;
+					}
+					if (nblk > 1 && B.full[1] * 3 > bs && lz_precheck_passes(T, keys1, B.full[1])) {
+						const RawBlock e = load_raw_block(b, T);
+						if (lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[1]) && !lz_repeats_reject(lds, M, e.e, B.full[1]))
+							lzq |= 2u;
+					}
 				}
 				if (!lzq) {
 					const uint32_t base = sink.base(), size0 = hs + B.full[0], size1 = nblk > 1 ? hs + B.full[1] : 0u;
-					WV_MARK("image_reset");
-					image_reset(lds, M, base, size0 + size1);
-					slot_rows_emit(lds, M, T, R, P, B, base, base + size0);
+					if (sink.writes) {
+						WV_MARK("image_reset");
+						image_reset(lds, M, base, size0 + size1);
+						slot_rows_emit(lds, M, T, R, P, B, base, base + size0);
+					}
 					WV_MARK("stream_append");
 					sink.append(lds, M, size0 + size1);
 					WV_MARK("block_end");
@@ -264,17 +248,21 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 }
 
 // ... into a staging stream at stage (16-byte aligned, room for nblocks * max_block_bytes(T) + 16); returns the bytes
+// (stage == nullptr: nothing is written, only the bytes are counted)
 WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true)
 {
 	StreamSink sink;
 	sink.rs.base = stage;
 	sink.rs.pos = 0;
+	sink.writes = stage != nullptr;
 	encode_blocks_to(sink, lds, L, T, src, nblocks, slots);
-	stream_flush(sink.rs, lds, L.out);
+	if (sink.writes)
+		stream_flush(sink.rs, lds, L.out);
 	return sink.rs.pos;
 }
-// HBM -> HBM copy of n bytes by one wave with 16-byte stores; src may be read up to 31 bytes past src + n
-// (and down to src & ~15), so it is only used on staging buffers that carry that slack.
+// HBM -> HBM copy of n bytes by one wave with 16-byte stores.  The source is read in aligned 16-byte groups, each of which
+// holds at least one byte of [src, src + n): such a load may cover up to 15 bytes in front of src or behind src + n, but
+// never leaves the page of a byte that belongs to the buffer.
 // dwords DSEL .. DSEL + 4 of {a, b}, shifted right by sh bits: 16 bytes that start (4 * DSEL + sh / 8) bytes into a
 template <uint32_t DSEL>
 WV_FN U128 funnel128(const U128& a, const U128& b, uint32_t sh)
@@ -300,35 +288,31 @@ WV_FN U128 funnel128(const U128& a, const U128& b, uint32_t sh)
 	return v;
 }
 // `groups` 16-byte groups to the aligned address d, from the bytes that start smis = 4 * DSEL + sh / 8 bytes behind the
-// aligned address sbase.  Four rounds of 64 groups at a time: all their loads are requested before the first store, so
-// the four rounds cost one memory round trip.
+// aligned address sbase.  COPY_ROUNDS rounds of 64 groups at a time: all their loads are requested before the first
+// store, so the rounds cost one memory round trip.
+#ifndef STENOS_COPY_ROUNDS
+#define STENOS_COPY_ROUNDS 2
+#endif
+constexpr uint32_t COPY_ROUNDS = STENOS_COPY_ROUNDS;
 template <uint32_t DSEL>
 WV_FN void copy_groups(uint8_t* d, const uint8_t* sbase, uint32_t groups, uint32_t sh, bool aligned)
 {
 	const U32 lane = lane_id();
-	for (uint32_t o = 0; o < groups; o += 256) {
-		U128 a0, a1, a2, a3, b0, b1, b2, b3;
-		const U32 k0 = U32(o) + lane, k1 = k0 + 64u, k2 = k0 + 128u, k3 = k0 + 192u;
-		const Pred p0 = k0 < U32(groups), p1 = k1 < U32(groups), p2 = k2 < U32(groups), p3 = k3 < U32(groups);
-		a0 = gld128(sbase, k0 * 16u, p0);
-		a1 = gld128(sbase, k1 * 16u, p1);
-		a2 = gld128(sbase, k2 * 16u, p2);
-		a3 = gld128(sbase, k3 * 16u, p3);
-		if (aligned) {
-			gst128(d, k0 * 16u, a0, p0);
-			gst128(d, k1 * 16u, a1, p1);
-			gst128(d, k2 * 16u, a2, p2);
-			gst128(d, k3 * 16u, a3, p3);
-			continue;
+	for (uint32_t o = 0; o < groups; o += 64 * COPY_ROUNDS) {
+		U128 a[COPY_ROUNDS], b[COPY_ROUNDS];
+		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+			const U32 k = U32(o + 64 * q) + lane;
+			a[q] = gld128(sbase, k * 16u, k < U32(groups));
 		}
-		b0 = gld128(sbase, k0 * 16u + 16u, p0);
-		b1 = gld128(sbase, k1 * 16u + 16u, p1);
-		b2 = gld128(sbase, k2 * 16u + 16u, p2);
-		b3 = gld128(sbase, k3 * 16u + 16u, p3);
-		gst128(d, k0 * 16u, funnel128<DSEL>(a0, b0, sh), p0);
-		gst128(d, k1 * 16u, funnel128<DSEL>(a1, b1, sh), p1);
-		gst128(d, k2 * 16u, funnel128<DSEL>(a2, b2, sh), p2);
-		gst128(d, k3 * 16u, funnel128<DSEL>(a3, b3, sh), p3);
+		if (!aligned)
+			for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+				const U32 k = U32(o + 64 * q) + lane;
+				b[q] = gld128(sbase, k * 16u + 16u, k < U32(groups));
+			}
+		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+			const U32 k = U32(o + 64 * q) + lane;
+			gst128(d, k * 16u, aligned ? a[q] : funnel128<DSEL>(a[q], b[q], sh), k < U32(groups));
+		}
 	}
 }
 WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)

@@ -172,16 +172,25 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 		if (posix_memalign((void**)&stage, 64, s_fused * FUSED_WAVES * (size_t)run_cap + 64))
 			return (size_t)-3;
 		uint8_t* wlds = alloc_lds(FUSED_WAVES * L.total);
+		bool guess_copy = false;
 		for (uint64_t s = 0; s < s_fused; ++s) { // encode_superblocks
-			uint32_t run_size[FUSED_WAVES], code;
-			for (uint32_t w = 0; w < FUSED_WAVES; ++w) {
-				uint32_t b0, b1;
-				fused_run_range(j.bps, w, &b0, &b1);
-				run_size[w] = encode_run(wlds + w * L.total, L, j.T, src + (s * j.bps + b0) * bs, b1 - b0, stage + (s * FUSED_WAVES + w) * (size_t)run_cap, g_slots != 0);
-				if (run_size[w] + 48 > run_cap)
-					return (size_t)-1;
+			uint32_t run_size[FUSED_WAVES], code = 0, size = 0;
+			for (int attempt = 0;; ++attempt) {
+				const bool measure = guess_copy && attempt == 0; // after a superblock that became a copy: sizes first
+				for (uint32_t w = 0; w < FUSED_WAVES; ++w) {
+					uint32_t b0, b1;
+					fused_run_range(j.bps, w, &b0, &b1);
+					run_size[w] = encode_run(wlds + w * L.total, L, j.T, src + (s * j.bps + b0) * bs, b1 - b0, measure ? nullptr : stage + (s * FUSED_WAVES + w) * (size_t)run_cap,
+								 g_slots != 0);
+					if (run_size[w] + 48 > run_cap)
+						return (size_t)-1;
+				}
+				size = fused_superblock_size(j, run_size, &code);
+				if (measure && code != 6)
+					continue;
+				guess_copy = code == 6;
+				break;
 			}
-			const uint32_t size = fused_superblock_size(j, run_size, &code);
 			sboff[s] = carry; // chain_scanner
 			for (uint32_t w = 0; w < FUSED_WAVES; ++w)
 				fused_store(j, s, w, carry, run_size, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
@@ -267,7 +276,6 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	return result;
 }
 
-void emul_copy_g2g(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g(dst, src, (uint32_t)n); }
 void emul_copy_g2g_wide(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g_wide(dst, src, (uint32_t)n); }
 
 size_t emul_lds_bytes_encode(size_t T) { return make_layout((uint32_t)T, true).total; }

@@ -24,8 +24,6 @@ def emul():
     lib.emul_block_compress.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_int]
     lib.emul_block_decompress.restype = c_size_t
     lib.emul_block_decompress.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int]
-    lib.emul_copy_g2g.restype = None
-    lib.emul_copy_g2g.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.emul_copy_g2g_wide.restype = None
     lib.emul_copy_g2g_wide.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.emul_set_fused.restype = None
@@ -69,27 +67,15 @@ def test_truncated_streams_are_rejected_not_overrun(oracle, emul):
             assert has_error(r3) or (cut == 0 and r3 == 0), (kind, cut, r3)
 
 
-def test_copy_any_alignment(emul):
-    rng = np.random.default_rng(0)
-    src = rng.integers(0, 256, size=5000, dtype=np.uint8)
-    for so in range(0, 8):
-        for do in range(0, 5):
-            for n in (0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1026, 3000):
-                dst = np.zeros(4096, dtype=np.uint8)
-                emul.emul_copy_g2g(np_ptr(dst) + do, np_ptr(src) + so, n)
-                assert np.array_equal(dst[do:do + n], src[so:so + n]), (so, do, n)
-                assert not dst[:do].any() and not dst[do + n:].any(), (so, do, n)
-
-
 def test_wide_copy_any_alignment(emul):
-    """copy_g2g_wide (staging run -> frame): every source / destination misalignment, sizes around the
-    16-byte group; the source buffer carries the slack the routine is allowed to read."""
+    """copy_g2g_wide (staging run -> frame, COPY superblocks): every source / destination misalignment, sizes around the
+    16-byte group and around the 256 groups of one round; nothing is written outside the destination range."""
     rng = np.random.default_rng(1)
     src = rng.integers(0, 256, size=6000, dtype=np.uint8)
     for so in range(0, 17):
         for do in range(0, 18):
-            for n in (0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 1023, 1040, 3001):
-                dst = np.zeros(4096, dtype=np.uint8)
+            for n in (0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 1023, 1040, 3001, 4095, 4113, 5000):
+                dst = np.zeros(6000, dtype=np.uint8)
                 emul.emul_copy_g2g_wide(np_ptr(dst) + do, np_ptr(src) + so, n)
                 assert np.array_equal(dst[do:do + n], src[so:so + n]), (so, do, n)
                 assert not dst[:do].any() and not dst[do + n:].any(), (so, do, n)
@@ -221,3 +207,26 @@ def test_slot_rows_encoder_on_plane_mixtures(oracle, emul, T):
             r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
             assert emul.emul_last_fused() == 3
             assert r2 == r1 and np.array_equal(out[:r2], f1), (kind, seed)
+
+
+@pytest.mark.parametrize("T", [2, 4, 8])
+def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T):
+    """After a superblock that ended up as a copy the fused kernel only measures the next one and encodes it for real when
+    it does compress after all (kernels.hip, encode_superblocks): inputs that alternate between noise and compressible
+    stretches, cut in and off superblock boundaries."""
+    from _libs import oracle_compress
+
+    emul.emul_set_fused(1)
+    emul.emul_set_slots(1)
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    per = 131072 // (256 * T) * 256
+    for pattern in (("rand", "walk", "rand", "rand", "mixed", "walk", "rand"), ("walk", "rand", "walk"), ("rand", "rand", "burst")):
+        for cut in (per, per + per // 3):
+            data = np.concatenate([generate(kind, T, cut, 50 + i) for i, kind in enumerate(pattern)])
+            cap = oracle.so_bound(data.nbytes) + 5000
+            r1, f1 = oracle_compress(oracle, data, T, 1, cap)
+            out = np.zeros(cap, dtype=np.uint8)
+            r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
+            assert emul.emul_last_fused() > 0
+            assert r2 == r1 and np.array_equal(out[:r2], f1), (pattern, cut)

@@ -153,6 +153,61 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and abs(d["compression_ratio"] - 2.52) < 0.01
+    x = d["sharded_exchange"]  # the gather of the segments to rank 0 and the sharded decode, run after the timed region
+    assert "gather_error" not in x, x
+    assert x["sharded_roundtrip_ok"] is True and x["gather_ms"] > 0 and x["gather_bytes_to_rank0"] > 0
+
+
+SHARDED_WORKER = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from stenos_amd.api import Stenos
+from stenos_amd.sharded import compress_sharded, decompress_sharded
+from stenos_amd.datagen import generate_torch
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+torch.cuda.set_device(0)
+st = Stenos(level=1)
+for kind, T, n in (("rand12", 4, 7 * 32768 + 1234), ("walk", 2, 11 * 65536 + 99), ("rand", 4, 5 * 32768 + 7)):
+    data = generate_torch(kind, T, n, 42, device="cuda:0")   # every rank holds the whole array, as compress_sharded expects
+    def compress(chunk):
+        dst = torch.empty(st.bound(chunk.numel()), dtype=torch.uint8, device="cuda:0")
+        return dst[:st.compress(chunk, T, dst)].clone()
+    frame = compress_sharded(compress, data, T)
+    rank0 = dist.get_rank() == 0
+    if rank0:
+        assert torch.equal(frame, compress(data)), "sharded frame differs from the single-GPU frame"
+    back = torch.empty_like(data)
+    def decompress(seg, nb):
+        out = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+        assert st.decompress(seg, T, seg.numel(), out) == nb
+        return out
+    whole, o0, o1 = decompress_sharded(decompress, frame if rank0 else None, st.frame_index(frame, T, frame.numel()) if rank0 else None, data.numel(), T,
+                                       "cuda:0", gather_output=True)
+    if rank0:
+        assert torch.equal(whole, data), "sharded decode differs from the input"
+if dist.get_rank() == 0:
+    print("SHARDED_GPU_OK")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_codec_two_ranks_on_one_gpu(tmp_path):
+    """SURVEY 8e end to end through the GPU codec at level 1: two ranks (on the one GPU of the test box, gloo moving the
+    segments) compress their superblock ranges, rank 0 assembles the frame -- equal to the single-process frame -- cuts it
+    again with the device-side header walk, and both ranks decode their segments."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(SHARDED_WORKER.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "SHARDED_GPU_OK" in p.stdout
 
 
 @pytest.mark.gpu

@@ -192,6 +192,31 @@ def test_custom_block_size_and_private_api(lib, oracle):
     lib.stenos_destroy_context(c)
 
 
+def test_small_custom_superblocks_exceed_stenos_bound(lib, ref_det):
+    """With stenos_set_block_size(ctx, 0) a superblock is one block, so an incompressible frame carries one 4-byte header
+    per 256 elements and is larger than stenos_bound() assumes (superblocks of at least 64 KiB, stenos.h:37-42): the
+    frame must fit a roomy destination and must equal the reference's."""
+    c = lib.stenos_make_context()
+    assert lib.stenos_set_block_size(c, 0) == 0
+    data = generate("rand", 4, 300_000, 9)
+    assert data.nbytes + 4 * (data.nbytes // 1024 + 1) + 12 > lib.stenos_bound(data.nbytes)
+    out = np.zeros(2 * data.nbytes, dtype=np.uint8)
+    r = lib.stenos_compress_generic(c, np_ptr(data), 4, data.nbytes, np_ptr(out), out.nbytes)
+    assert not has_error(r) and r > lib.stenos_bound(data.nbytes)
+    back = np.zeros(data.nbytes, dtype=np.uint8)
+    assert lib.stenos_decompress_generic(c, np_ptr(out), 4, r, np_ptr(back), back.nbytes) == data.nbytes
+    assert np.array_equal(back, data)
+    if ref_det is not None:
+        rc = ref_det.stenos_make_context()
+        ref_det.stenos_set_block_size(rc, 0)
+        ref_det.stenos_set_level(rc, 1)
+        exp = np.zeros(2 * data.nbytes, dtype=np.uint8)
+        r2 = ref_det.stenos_compress_generic(rc, np_ptr(data), 4, data.nbytes, np_ptr(exp), exp.nbytes)
+        ref_det.stenos_destroy_context(rc)
+        assert r2 == r and np.array_equal(exp[:r], out[:r])
+    lib.stenos_destroy_context(c)
+
+
 def test_unsupported_requests_fail_loudly(lib):
     c = lib.stenos_make_context()
     data = generate("walk", 4, 5000, 1)

@@ -29,7 +29,7 @@ WORKER = textwrap.dedent("""
     import os, sys, numpy as np, torch, torch.distributed as dist
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
     from stenos_amd.api import load_library
-    from stenos_amd.sharded import compress_sharded
+    from stenos_amd.sharded import compress_sharded, decompress_sharded, walk_frame_host
     from stenos_amd.datagen import generate
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     lib = load_library()
@@ -49,6 +49,18 @@ WORKER = textwrap.dedent("""
         f = frame.numpy()
         assert lib.stenos_decompress(f.ctypes.data, T, f.nbytes, back.ctypes.data, back.nbytes) == data.nbytes
         assert np.array_equal(back, data)
+    # the decode half: rank 0 cuts the frame at the range boundaries, every rank decodes its own segment
+    def decompress(local, nbytes):
+        f = local.numpy()
+        out = np.zeros(nbytes, dtype=np.uint8)
+        assert lib.stenos_decompress(f.ctypes.data, T, f.nbytes, out.ctypes.data, nbytes) == nbytes
+        return torch.from_numpy(out)
+    rank0 = dist.get_rank() == 0
+    whole, o0, o1 = decompress_sharded(decompress, frame if rank0 else None, walk_frame_host(frame, T) if rank0 else None, data.nbytes, T, "cpu",
+                                       gather_output=True)
+    assert 0 <= o0 <= o1 <= data.nbytes and (o0 % 131072 == 0)
+    if rank0:
+        assert np.array_equal(whole.numpy(), data), "sharded decode differs from the input"
         print("SHARDED_OK")
     dist.barrier()
     dist.destroy_process_group()
