@@ -1425,8 +1425,6 @@ size_t stenos_private_compress_block(stenos_context* ctx, const void* src, size_
 	size_t e = check_supported(ctx, bytesoftype, ctx->level);
 	if (is_err(e))
 		return e;
-	if (needs_strategy(bytesoftype, ctx->level)) // single-superblock strategy calls: not wired yet (cvector at levels >= 2)
-		return STENOS_ERROR_INVALID_PARAMETER;
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
 	if (bytes > super_block_size || super_block_size >= STENOS_MAX_BLOCK_BYTES)
@@ -1443,6 +1441,20 @@ size_t stenos_private_compress_block(stenos_context* ctx, const void* src, size_
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	if (needs_strategy(bytesoftype, ctx->level)) {
+		// levels >= 2 and bytesoftype 1 (stenos::cvector<char>, cvector at higher levels): the strategy layer on this one
+		// superblock, as a frame of one superblock whose 8-byte header is dropped; the superblock sees the caller's capacity
+		f.header = 8;
+		f.shift = 0;
+		HostBuf& tmp = ctx->h_out;
+		if (!tmp.ensure(dst_size + 8 + 64))
+			return STENOS_ERROR_ALLOC;
+		const size_t r = compress_strategy(ctx, (const uint8_t*)src, ctx->in.as<uint8_t>(), bytesoftype, bytes, tmp.data(), dst_size + 8, ctx->level, f, nullptr);
+		if (is_err(r))
+			return r;
+		memcpy(dst, tmp.data() + 8, r - 8);
+		return r - 8;
+	}
 	e = enqueue_compress(ctx, ctx->in.as<uint8_t>(), bytesoftype, bytes, ctx->out.as<uint8_t>(), dst_size, ctx->level, f, false, nullptr);
 	if (is_err(e))
 		return e;
@@ -1462,7 +1474,6 @@ size_t stenos_private_compress_block(stenos_context* ctx, const void* src, size_
 size_t stenos_private_decompress_block(stenos_context* ctx, const void* src, size_t bytesoftype, size_t super_block_size, size_t bytes, void* dst,
 				       size_t dst_size)
 {
-	(void)super_block_size;
 	const uint8_t* in = (const uint8_t*)src;
 	if (bytes < 4) // stenos.cpp:792-793
 		return STENOS_ERROR_SRC_OVERFLOW;
@@ -1483,6 +1494,18 @@ size_t stenos_private_decompress_block(stenos_context* ctx, const void* src, siz
 			return STENOS_ERROR_ZSTD_INTERNAL;
 		size_t r = zstd().decompress(dst, dst_size, in + 4, csize);
 		return zstd().is_error(r) ? STENOS_ERROR_INVALID_INPUT : dst_size;
+	}
+	if (code >= 3 && code <= 5) {
+		// transposed / transposed + delta / block codec output, each under zstd (decompress_generic_superblock, stenos.cpp:700-740):
+		// the same machinery as for frames, given this superblock as a frame of one superblock of a custom size
+		if (dst_size == 0 || dst_size > super_block_size || super_block_size < bytesoftype * 256 || super_block_size >= STENOS_MAX_BLOCK_BYTES)
+			return STENOS_ERROR_INVALID_INPUT;
+		std::vector<uint8_t> frame(12 + 4 + csize);
+		frame[0] = 255;
+		put_le(frame.data() + 1, dst_size, 7);
+		put_le(frame.data() + 8, super_block_size, 4);
+		memcpy(frame.data() + 12, in, 4 + csize);
+		return stenos_decompress_generic(ctx, frame.data(), bytesoftype, frame.size(), dst, dst_size);
 	}
 	if (code != 1 || bytesoftype > kMaxT)
 		return STENOS_ERROR_INVALID_INPUT;

@@ -83,6 +83,9 @@ def bind_stenos_abi(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.stenos_decompress_generic.argtypes = [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_size_t]
     lib.stenos_get_info.restype = c_size_t
     lib.stenos_get_info.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p]
+    for f in (lib.stenos_private_compress_block, lib.stenos_private_decompress_block):
+        f.restype = c_size_t
+        f.argtypes = [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t]
     return lib
 
 

@@ -1,0 +1,39 @@
+"""Link-level checks of the drop-in boundary (tests/link): programs compiled against the C header and linked with
+-lstenos, run on the GPU box.  The binaries are built by tests/link/Makefile (__graft_entry__.build()) into build/."""
+import os
+import subprocess
+
+import pytest
+
+from _libs import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _binary(name):
+    path = os.path.join(ROOT, "build", name)
+    if not os.path.exists(path):
+        pytest.skip(f"build/{name} was not built (tests/link/Makefile)")
+    return path
+
+
+def test_c_program_against_the_header_and_the_library():
+    """include/stenos.h is valid C99, every symbol a C caller uses resolves in libstenos.so, and the calls work."""
+    p = subprocess.run([_binary("abi_link")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ABI_LINK_OK" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+
+
+def test_the_references_own_round_trip_test_runs_against_this_library():
+    """The reference's tests/tests_comp_decomp.cpp (bytesoftype 1..15 x same / sorted / random x levels 0..5 x threads 1..8 x
+    shrinking dst_size, tests_comp_decomp.cpp:93-211), compiled with the reference's own header and linked with this
+    library.  The whole matrix takes hours; it aborts at the first failure (STENOS_ABORT), so a bounded run that is still
+    going -- or has finished -- without an abort is a pass."""
+    try:
+        p = subprocess.run([_binary("ref_tests_comp_decomp")], capture_output=True, text=True, timeout=60)
+        out, rc = p.stdout, p.returncode
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+        rc = None
+    assert "Test error" not in out, out[-800:]
+    assert rc in (None, 0), (rc, out[-800:])
+    assert out.count("done") > 50, "the test did not get anywhere: " + out[-500:]

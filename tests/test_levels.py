@@ -112,3 +112,33 @@ def test_device_api_levels(lib):
         assert st.decompress(dst, T, csize, back) == src.numel()
         assert torch.equal(back, src)
         st.close()
+
+
+@pytest.mark.gpu
+@needs_zstd_149
+@pytest.mark.parametrize("T,kind,level", [(4, "walk", 2), (4, "rand12", 3), (8, "sine", 2), (1, "smooth8", 1), (1, "smooth8", 3), (1, "rand", 5), (2, "burst", 4), (4, "dict16", 9)])
+def test_private_single_superblock_api_at_all_levels(lib, ref_det, T, kind, level):
+    """stenos_private_compress_block / stenos_private_decompress_block as stenos::cvector calls them (cvector.hpp:1397-1416),
+    at levels >= 2 and for bytesoftype 1: the superblock is the reference's, and it decodes, for chunk sizes of 256 << shift
+    elements with and without a short last chunk."""
+    if ref_det is None:
+        pytest.skip("oracle/_ref not built")
+    c = lib.stenos_make_context()
+    rc = ref_det.stenos_make_context()
+    lib.stenos_set_level(c, level)
+    ref_det.stenos_set_level(rc, level)
+    for shift, used in ((0, 256), (2, 1024), (4, 4096), (4, 3000), (6, 16384)):
+        sb = (256 << shift) * T
+        data = generate(kind, T, used, 11 + shift)
+        nb = data.nbytes
+        exp = np.zeros(nb + 64, dtype=np.uint8)
+        out = np.full(nb + 64 + 64, 0xA5, dtype=np.uint8)
+        r1 = ref_det.stenos_private_compress_block(rc, np_ptr(data), T, sb, nb, np_ptr(exp), nb + 64)
+        r2 = lib.stenos_private_compress_block(c, np_ptr(data), T, sb, nb, np_ptr(out), nb + 64)
+        assert not has_error(r1) and r1 == r2, (shift, used, hex(r1), hex(r2))
+        assert np.array_equal(exp[:r1], out[:r2]) and (out[nb + 64:] == 0xA5).all(), (shift, used, int(exp[0]))
+        back = np.zeros(nb, dtype=np.uint8)
+        assert lib.stenos_private_decompress_block(c, np_ptr(out), T, sb, r2, np_ptr(back), nb) == nb
+        assert np.array_equal(back, data), (shift, used)
+    lib.stenos_destroy_context(c)
+    ref_det.stenos_destroy_context(rc)
