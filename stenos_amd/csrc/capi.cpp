@@ -284,11 +284,10 @@ size_t plan_frame(const stenos_context_s* ctx, size_t T, size_t bytes, int level
 	return 0;
 }
 
-// What this build cannot do yet is refused loudly instead of being routed to a CPU path.
+// What this build cannot do is refused loudly instead of being routed to a CPU path.
 size_t check_supported(const stenos_context_s* ctx, size_t T, int level)
 {
-	if (ctx->max_nanoseconds) // time-limited mode: wall-clock dependent output
-		return STENOS_ERROR_INVALID_PARAMETER;
+	(void)ctx;
 	if (level >= 1 && T > kMaxT) // the block does not fit the per-wave LDS budget of the codec
 		return STENOS_ERROR_INVALID_PARAMETER;
 	return 0;
@@ -862,6 +861,8 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
 	const int level = ctx->level;
+	if (ctx->max_nanoseconds) // the time limit is a feature of the host-pointer ABI (compress_timed); these entry points take none
+		return STENOS_ERROR_INVALID_PARAMETER;
 	FramePlan f;
 	size_t e = plan_frame(ctx, T, bytes, level, f);
 	if (is_err(e))
@@ -1218,12 +1219,97 @@ size_t stenos_memory_footprint(stenos_context* ctx)
 int stenos_has_error(size_t r) { return r >= STENOS_LAST_ERROR_CODE; }
 size_t stenos_bound(size_t bytes) { return stenos::compress_bound(bytes); }
 
+// Time-limited compression (stenos_set_max_nanoseconds).  The reference keeps adjusting its level to the time that is left:
+// per block inside the block codec, down to blocks stored as they are (block_compress.h:1024-1075, 1158-1176), per
+// superblock for the zstd stages (zstd_wrapper.h:118-174, stenos.cpp:471-490), on superblocks sized after the thread
+// count (stenos.cpp:126-149), and finishes with plain copies when nothing else fits.  Its output depends on the clock and
+// is not reproducible.  Here the unit of adjustment is a slice of whole superblocks (default size, frame byte 0): before
+// each slice the host clock and the rates measured so far decide whether the slice goes through zstd on top of the block
+// codec (level 2, when the context's level allows it), through the block codec (level 1) or is stored as copies; a slice
+// is only compressed when copying everything behind it would still fit the time that is left.  Every frame decodes with
+// the ordinary decoder.
+size_t compress_timed(stenos_context* ctx, const uint8_t* src, size_t T, size_t bytes, uint8_t* out, size_t dst_size)
+{
+	using clock = std::chrono::steady_clock;
+	const auto start = clock::now();
+	const double budget = (double)ctx->max_nanoseconds * 1e-9;
+	if (T == 0 || T >= STENOS_MAX_BYTESOFTYPE)
+		return STENOS_ERROR_INVALID_BYTESOFTYPE;
+	const size_t sb = base_superblock(T * 256);
+	if (dst_size < 8)
+		return STENOS_ERROR_DST_OVERFLOW;
+	out[0] = 0;
+	put_le(out + 1, bytes, 7);
+	// slices of 1/16 of the input, between 4 and 64 MiB: enough of them to adjust, each large enough for the device
+	size_t slice = bytes / 16;
+	slice = slice < ((size_t)4 << 20) ? ((size_t)4 << 20) : (slice > ((size_t)64 << 20) ? ((size_t)64 << 20) : slice);
+	slice = (slice + sb - 1) / sb * sb;
+	const int top = ctx->level > 2 ? 2 : ctx->level; // levels above 2 change the superblock size of a frame: not inside one frame
+	double rate[3] = { 6e9, 12e9, 1e9 }; // bytes per second of a slice stored as copies / at level 1 / at level 2: first guesses, then measured
+	const int saved_level = ctx->level;
+	const uint64_t saved_ns = ctx->max_nanoseconds;
+	const size_t saved_shift = ctx->custom_shift; // (the reference's time-limited frames choose their superblock size themselves, too)
+	size_t off = 8, pos = 0, result = 0;
+	while (pos < bytes) {
+		const size_t n = bytes - pos < slice ? bytes - pos : slice;
+		const double left = budget - std::chrono::duration<double>(clock::now() - start).count();
+		const double rest = (double)(bytes - pos - n) / rate[0]; // what copying everything behind this slice takes
+		int level = 0;
+		if (top >= 1 && T <= kMaxT && left > 0 && (double)n / rate[1] + rest <= left)
+			level = 1;
+		if (level == 1 && top >= 2 && zstd().ok && (double)n / rate[2] + rest <= left * 0.5)
+			level = 2;
+		const auto t0 = clock::now();
+		size_t r;
+		if (level == 0) {
+			const size_t nsb = n / sb + (n % sb ? 1 : 0);
+			if (dst_size - off < n + 4 * nsb) {
+				result = STENOS_ERROR_DST_OVERFLOW;
+				break;
+			}
+			for (size_t s = 0; s < nsb; ++s) { // compress_memcpy (stenos.cpp:363-374)
+				const size_t m = n - s * sb < sb ? n - s * sb : sb;
+				out[off] = 6;
+				put_le(out + off + 1, m, 3);
+				memcpy(out + off + 4, src + pos + s * sb, m);
+				off += 4 + m;
+			}
+			r = 0;
+		}
+		else {
+			// the slice as a frame of its own, written so that its 8-byte header falls on the 8 bytes in front of `off`
+			uint8_t keep[8];
+			memcpy(keep, out + off - 8, 8);
+			ctx->level = level;
+			ctx->max_nanoseconds = 0;
+			ctx->custom_shift = STENOS_NO_BLOCK_SHIFT;
+			r = stenos_compress_generic(ctx, src + pos, T, n, out + off - 8, dst_size - off + 8);
+			ctx->level = saved_level;
+			ctx->max_nanoseconds = saved_ns;
+			ctx->custom_shift = saved_shift;
+			memcpy(out + off - 8, keep, 8);
+			if (is_err(r)) {
+				result = r;
+				break;
+			}
+			off += r - 8;
+		}
+		const double took = std::chrono::duration<double>(clock::now() - t0).count();
+		if (took > 0)
+			rate[level] = 0.5 * rate[level] + 0.5 * (double)n / took;
+		pos += n;
+	}
+	return is_err(result) ? result : off;
+}
+
 size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t bytesoftype, size_t bytes, void* dst, size_t dst_size)
 {
 	FramePlan f;
 	size_t e = plan_frame(ctx, bytesoftype, bytes, ctx->level, f);
 	if (is_err(e))
 		return e;
+	if (ctx->max_nanoseconds && bytes && ctx->level)
+		return compress_timed(ctx, (const uint8_t*)src, bytesoftype, bytes, (uint8_t*)dst, dst_size);
 	e = check_supported(ctx, bytesoftype, ctx->level);
 	if (is_err(e))
 		return e;
