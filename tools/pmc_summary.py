@@ -30,8 +30,6 @@ for p in sorted(newest.values()):
         full_names[name][(r["Counter_Name"], k)] += 1
 out = {}
 for name, cs in agg.items():
-    # int32 launches two instantiations of encode_superblocks per call (one returns at once): their
-    # counters add up to one launch, so the divisor is the number of rows of one instantiation
     first = next(iter(cs))
     launches = max(n for (c, k), n in full_names[name].items() if c == first)
     out[name] = {c: sum(v) / launches for c, v in cs.items()}
@@ -50,6 +48,18 @@ for k in ("encode_superblocks", "encode_blocks", "pack_frame", "decode_superbloc
         res[f"{k}_hbm_read_bytes"] = int(scale * 2 * out[k]["FETCH_SIZE"] * 1024)
         res[f"{k}_hbm_write_bytes"] = int(scale * out[k]["WRITE_SIZE"] * 1024)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json"), "w") as f:
+    json.dump(res, f, indent=1)
+import subprocess  # noqa: E402
+
+try:
+    build = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "stenos_amd/csrc"], text=True).strip():
+        build += "+local changes"
+except Exception:
+    build = "unknown"
+res["profile"] = f"{tag}_pmc_counters.json"
+res["build"] = build  # the sources the counters were collected from: bench.py quotes it next to roofline.traffic
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json"), "w") as f:
     json.dump(res, f, indent=1)
 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
