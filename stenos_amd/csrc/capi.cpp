@@ -488,11 +488,14 @@ size_t host_copy_superblock(const uint8_t* src, size_t bytes, uint8_t* dst, size
 // Host side worker threads for the zstd stages of levels >= 2 (one superblock per task).
 unsigned host_threads()
 {
-	unsigned n = std::thread::hardware_concurrency();
-	if (const char* e = getenv("STENOS_HOST_THREADS"))
-		if (atoi(e) > 0)
-			n = (unsigned)atoi(e);
-	return n > 64 ? 64 : n < 1 ? 1 : n;
+	static const unsigned threads = [] { // (read once: no environment look-ups on the call path)
+		unsigned n = std::thread::hardware_concurrency();
+		if (const char* e = getenv("STENOS_HOST_THREADS"))
+			if (atoi(e) > 0)
+				n = (unsigned)atoi(e);
+		return n > 64 ? 64u : n < 1 ? 1u : n;
+	}();
+	return threads;
 }
 
 // Persistent workers (created on first use, joined at unload): a batch of superblocks is a few milliseconds of
@@ -1672,8 +1675,9 @@ size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes)
 	const size_t nblocks = bytes / bs + 2;
 	const size_t nsb = bytes / sb + 2;
 	const uint32_t T = (uint32_t)bytesoftype;
-	// the arena: staging streams of the fused encoder (about the input size) or, where that kernel does not apply,
-	// one padded slot per block; then 12 bytes of tables per block and 37 per superblock (default superblock size)
+	// the arena: staging buffers of the fused encoder (two per resident workgroup, whatever the input size) plus the slots of
+	// the last superblocks or, where that kernel does not apply, one padded slot per block; then 12 bytes of tables per block
+	// and 37 per superblock (default superblock size).  (A destination below stenos_bound() sends every block through slots.)
 	const size_t arena = stenos_k_fused_supported(T) ? stenos_k_fused_stage_bytes(T, (uint32_t)(sb / bs), nsb) + 2 * (sb / bs + 1) * stenos_k_slot_stride(T)
 							 : nblocks * (size_t)stenos_k_slot_stride(T);
 	return arena + nblocks * 12 + nsb * 37 + 4096;
