@@ -23,7 +23,16 @@ using namespace wv;
 enum { PLANE_SAME = 0, PLANE_RAW = 1, PLANE_NORMAL = 2, PLANE_NORMAL_RLE = 3 };
 enum { BLOCK_COPY = 252, BLOCK_LZ = 253, BLOCK_PARTIAL = 254 };
 constexpr uint32_t LZ_NONE = 0xFFFFFFFFu;
-constexpr uint32_t MAX_T = 64; // largest bytesoftype handled by the LDS-resident codec
+// Largest bytesoftype of the LDS-resident codec.  Above it (kernels_wide.hip, -DSTENOS_WIDE) the same source runs with the
+// wave's scratch in HBM: a block of 256*T bytes, its image and its tables no longer fit the LDS of a workgroup.
+#ifdef STENOS_WIDE
+constexpr uint32_t MAX_T = 65534; // stenos.h:65
+#else
+constexpr uint32_t MAX_T = 64;
+#endif
+constexpr uint32_t LZ_MAX_T = 512; // lz_compress_generic gives up above (15-bit distances, lz_compress.h:281-283)
+// plinfo entry: type | size_or_offset << PL_SHIFT (offsets reach 280 * 65534)
+constexpr uint32_t PL_SHIFT = 4, PL_TYPE = 15;
 
 // Byte offsets of the regions of one wave's LDS scratch.
 struct Layout {
@@ -33,7 +42,7 @@ struct Layout {
 	uint32_t plinfo;  // T entries of 4 bytes
 	uint32_t aux;     // 64 entries of 8 bytes: row statistics of the current plane group (dead once the planes are analysed)
 	uint32_t lz;      // mini-LZ chain count*4 + cur count*4, on top of aux; its 256-entry table uses the not yet written image
-	uint32_t skip;    // mini-LZ: one bit per group that was left raw (32 bytes)
+	uint32_t skip;    // mini-LZ: one bit per group that was left raw (32 bytes up to bytesoftype 64)
 	uint32_t tab;     // 1 KiB for the tables of the mini-LZ (hash table, counters and bitmaps of its rejection tests): the image, which is
 	                  // only written once they are dead
 	uint32_t total;
@@ -42,6 +51,11 @@ struct Layout {
 WV_HD uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 WV_HD uint32_t lz_width(uint32_t T) { return (T % 8 == 0) ? 8u : 4u; } // lz_compress.h:285-290 for T%4==0
 WV_HD uint32_t header_bytes(uint32_t T) { return (T + 1) >> 1; }
+WV_HD uint32_t lz_skip_bytes(uint32_t T) // one bit per group of 8 values
+{
+	const uint32_t bytes = align16(256 * T / lz_width(T) / 64);
+	return (T % 4 == 0 && T <= LZ_MAX_T && bytes > 32) ? bytes : 32;
+}
 // a partial block can take 1 + T/2 + T*(8 + 15*17) + (16*T - 1) bytes, more than a full one
 // bytesoftype 2: two full blocks of a batch are written into the image together (slot_codec.h)
 WV_HD uint32_t out_capacity(uint32_t T) { return T == 2 ? 1088u : align16(280 * T + header_bytes(T) + 40); }
@@ -61,13 +75,13 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	L.plinfo = o;
 	o += align16(T * 4);
 	L.skip = o;
-	o += 32;
+	o += lz_skip_bytes(T);
 	L.aux = o;
 	L.lz = o;
 	uint32_t scratch = 64 * 8;
 	if (T == 2 || T == 4)
 		scratch = 4 * 256; // the four plane slots of slot_codec.h
-	if (with_lz && T % 4 == 0) {
+	if (with_lz && T % 4 == 0 && T <= LZ_MAX_T) {
 		const uint32_t count = 256 * T / lz_width(T);
 		scratch = count * 8 > scratch ? count * 8 : scratch;
 	}
@@ -302,7 +316,7 @@ WV_FN void analyse_rows_int32(Lds lds, const Layout& L, const PlaneRegs& regs)
 }
 
 // rowinfo entry: lo = hdr | min<<8 | poff<<16 ; hi = minpos | emitmin<<12 | eq<<13
-// plinfo entry : type | size_or_offset<<8
+// plinfo entry : type | size_or_offset<<PL_SHIFT
 
 // Stage 2 of the analysis, on row lanes: lane 16p + r decides row r of plane g + p from the statistics in L.aux
 // (entry p*16 + r) and leaves the row's header, minimum and offsets in L.rowinfo (entry (g + p)*16 + r).
@@ -368,20 +382,20 @@ WV_FN void analyse_stage2(Lds lds, const Layout& L, uint32_t g, uint32_t np, boo
 	lds_st32(lds, ri, hdr | (minv << 8) | (poff << 16), valid);
 	lds_st32(lds, ri + 4u, minpos | sel(emit, U32(1u << 12), U32(0u)) | sel(eq, U32(1u << 13), U32(0u)), valid);
 	if (praw) {
-		const U32 pinfo = type | (size << 8);
+		const U32 pinfo = type | (size << PL_SHIFT);
 		for (uint32_t k = 0; k < 4; ++k) { // constant indices keep praw in scalar registers
 			const uint32_t v = readlane(pinfo, 16 * k);
 			praw[k] = k < np ? v : praw[k];
 		}
 	}
 	else
-		lds_st32(lds, U32(L.plinfo) + (U32(g) + pl) * 4u, type | (size << 8), valid & (r == U32(0u)));
+		lds_st32(lds, U32(L.plinfo) + (U32(g) + pl) * 4u, type | (size << PL_SHIFT), valid & (r == U32(0u)));
 	wave_sync();
 }
 
 // Analyse the planes [g, g+np) (np <= 4).  rle: full-block mode (rle + raw override enabled);
 // lines: number of rows that will be emitted (16 for full blocks).
-// praw: when given (bytesoftype <= 4, a single group), the planes' type | size << 8 come back as scalars instead of
+// praw: when given (bytesoftype <= 4, a single group), the planes' type | size << PL_SHIFT come back as scalars instead of
 // going through L.plinfo.
 WV_FN void analyse_group(Lds lds, const Layout& L, uint32_t T, uint32_t g, uint32_t np, bool rle, uint32_t lines, const PlaneRegs& regs,
 			 uint32_t* praw = nullptr)
@@ -430,7 +444,7 @@ struct SameScan {
 };
 // What the frame assembly needs to know about an encoded block to reproduce the reference's
 // capacity rules (block_compress.h:1214, 1225, 1241; block_compress_partial :984, 994, 1013):
-//   info = full | need << 15 | eligible << 30 | lz_ok << 31
+//   info = full | eligible << 30 | lz_ok << 31
 //   full : sum of the plane sizes (the non-LZ encoding is header_bytes + full)
 //   need : bytes of capacity, counted from the block's first byte, that the non-LZ encoding requires
 //          (the largest of the reference's "dst + x > dst_end" tests)
@@ -438,9 +452,9 @@ struct SameScan {
 struct BlockInfo {
 	uint32_t size; // bytes of the emitted encoding
 	uint32_t info;
+	uint32_t need;
 };
-WV_HD uint32_t info_full(uint32_t info) { return info & 0x7FFFu; }
-WV_HD uint32_t info_need(uint32_t info) { return (info >> 15) & 0x7FFFu; }
+WV_HD uint32_t info_full(uint32_t info) { return info & 0x3FFFFFFFu; }
 WV_HD bool info_eligible(uint32_t info) { return (info >> 30) & 1u; }
 WV_HD bool info_lz_ok(uint32_t info) { return (info >> 31) & 1u; }
 
@@ -452,42 +466,47 @@ WV_HD bool info_lz_ok(uint32_t info) { return (info >> 31) & 1u; }
 WV_FN uint32_t plane_offsets(Lds lds, const Layout& L, uint32_t T, bool full_block, uint32_t lines, uint32_t* need)
 {
 	const U32 lane = lane_id();
-	const Pred valid = lane < U32(T);
-	U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
-	U32 type = pi & 0xFFu;
-	U32 size = pi >> 8;
-	U32 incl = wave_incl_scan(size);
-	U32 off = U32(header_bytes(T)) + incl - size;
-	lds_st32(lds, U32(L.plinfo) + lane * 4u, type | (off << 8), valid);
-	wave_sync();
-	const uint32_t full = readlane(incl, 63);
-	U32 req;
-	if (full_block)
-		req = sel(valid & (type != U32(PLANE_RAW)), off + size + 16u, U32(0u));
-	else {
-		const uint32_t nh = (lines + 1) >> 1;
-		req = sel(valid, sel(type == U32(PLANE_SAME), off + 1u, off + (size - nh + 8u) + 8u), U32(0u));
+	uint32_t full = 0, m = 0;
+	for (uint32_t c = 0; c < T; c += 64) { // 64 planes at a time
+		const U32 j = U32(c) + lane;
+		const Pred valid = j < U32(T);
+		U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + sel(valid, j, U32(0u)) * 4u), U32(0u));
+		U32 type = pi & PL_TYPE;
+		U32 size = pi >> PL_SHIFT;
+		U32 incl = wave_incl_scan(size);
+		U32 off = U32(header_bytes(T) + full) + incl - size;
+		lds_st32(lds, U32(L.plinfo) + j * 4u, type | (off << PL_SHIFT), valid);
+		U32 req;
+		if (full_block)
+			req = sel(valid & (type != U32(PLANE_RAW)), off + size + 16u, U32(0u));
+		else {
+			const uint32_t nh = (lines + 1) >> 1;
+			req = sel(valid, sel(type == U32(PLANE_SAME), off + 1u, off + (size - nh + 8u) + 8u), U32(0u));
+		}
+		const uint32_t mc = wave_max(req);
+		m = mc > m ? mc : m;
+		full += readlane(incl, 63);
 	}
-	uint32_t m = wave_max(req);
+	wave_sync();
 	const uint32_t whole = header_bytes(T) + full;
 	*need = m > whole ? m : whole;
 	return full;
 }
 
-// The same on scalars for bytesoftype <= 4: tab[k] = type | size << 8 on entry, type | offset << 8 on return.
+// The same on scalars for bytesoftype <= 4: tab[k] = type | size << PL_SHIFT on entry, type | offset << PL_SHIFT on return.
 WV_HD uint32_t plane_offsets_small(uint32_t T, bool full_block, uint32_t lines, uint32_t* tab, uint32_t* need)
 {
 	const uint32_t hs = header_bytes(T), nh = (lines + 1) >> 1;
 	uint32_t off = hs, m = 0;
 	for (uint32_t k = 0; k < T; ++k) {
-		const uint32_t type = tab[k] & 0xFFu, size = tab[k] >> 8;
+		const uint32_t type = tab[k] & PL_TYPE, size = tab[k] >> PL_SHIFT;
 		uint32_t req;
 		if (full_block)
 			req = type != PLANE_RAW ? off + size + 16u : 0u;
 		else
 			req = type == PLANE_SAME ? off + 1u : off + (size - nh + 8u) + 8u;
 		m = req > m ? req : m;
-		tab[k] = type | (off << 8);
+		tab[k] = type | (off << PL_SHIFT);
 		off += size;
 	}
 	*need = m > off ? m : off;
@@ -508,11 +527,13 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 			nib |= (tab[k] & 0xFu) << (4 * k);
 		lds_put_bits(out, U32(base * 8u), U32(nib), lane == U32(0u));
 	}
-	else {
-		Pred valid = lane < U32(T);
-		U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + lane * 4u), U32(0u));
-		lds_put_small(out, U32(base * 8u) + lane * 4u, pi & 0xFu, valid);
-	}
+	else
+		for (uint32_t c = 0; c < T; c += 64) {
+			const U32 j = U32(c) + lane;
+			Pred valid = j < U32(T);
+			U32 pi = sel(valid, lds_ld32(lds, U32(L.plinfo) + sel(valid, j, U32(0u)) * 4u), U32(0u));
+			lds_put_small(out, U32(base * 8u) + j * 4u, pi & 0xFu, valid);
+		}
 	// row lanes: row-header nibbles, mins, SAME byte
 	WV_MARK("emit_rowlanes");
 	for (uint32_t g = 0; g < T; g += 4) {
@@ -523,8 +544,8 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		U32 pi, type, pbase;
 		lds_ld64(lds, U32(L.rowinfo) + (U32(g) * 16u + lane) * 8u, lo, hi);
 		pi = tab ? row_select4(tab[0], tab[1], tab[2], tab[3]) : lds_ld32(lds, U32(L.plinfo) + sel(valid, U32(g) + pl, U32(0u)) * 4u);
-		type = pi & 0xFFu;
-		pbase = U32(base) + (pi >> 8); // byte offset of this plane in the image
+		type = pi & PL_TYPE;
+		pbase = U32(base) + (pi >> PL_SHIFT); // byte offset of this plane in the image
 		Pred normal = valid & ((type == U32(PLANE_NORMAL)) | (type == U32(PLANE_NORMAL_RLE)));
 		Pred act = r < U32(lines);
 		U32 hdr = lo & 0xFFu, minv = (lo >> 8) & 0xFFu;
@@ -549,8 +570,8 @@ WV_FN void emit_planes(Lds lds, const Layout& L, uint32_t T, uint32_t base, uint
 		if (regs.valid && j % 4 == 0 && j != cur.g)
 			cur = load_plane_regs(lds, L.in, T, j);
 		uint32_t pi = tab ? tab[j] : readlane(lds_ld32(lds, U32(L.plinfo + j * 4u)), 0);
-		uint32_t type = pi & 0xFFu;
-		uint32_t pbase = base + (pi >> 8);
+		uint32_t type = pi & PL_TYPE;
+		uint32_t pbase = base + (pi >> PL_SHIFT);
 		if (type == PLANE_SAME)
 			continue;
 		U32 w = fetch_plane_word(lds, L.in, T, j, cur);
@@ -774,9 +795,10 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 
 	uint32_t failed = 0, max_failed = 3, produced = 0;
 	bool once = false;
-	// skip bits (one per group, up to 256 groups)
+	// skip bits (one per group)
 	const uint32_t skipbits = L.skip;
-	lds_st32(lds, U32(skipbits) + lane * 4u, U32(0u), lane < U32(8u));
+	for (uint32_t o = 0; o < lz_skip_bytes(T); o += 256)
+		lds_st32(lds, U32(skipbits + o) + lane * 4u, U32(0u), U32(o) + lane * 4u < U32(lz_skip_bytes(T)));
 	wave_sync();
 	auto skipped = [&](const U32& h) -> Pred {
 		Pred has = h != U32(LZ_NONE);
@@ -925,9 +947,10 @@ WV_FN BlockInfo encode_full_block(Lds lds, const Layout& L, uint32_t T, bool all
 	uint32_t need;
 	WV_MARK("plane_offsets");
 	uint32_t full = small ? plane_offsets_small(T, true, 16, tab, &need) : plane_offsets(lds, L, T, true, 16, &need);
-	const bool eligible = T % 4 == 0 && full * 3 > 256 * T; // (:1210)
+	const bool eligible = T % 4 == 0 && T <= LZ_MAX_T && full * 3 > 256 * T; // (:1210; lz_compress.h:281-283)
 	BlockInfo r;
-	r.info = full | (need << 15) | (eligible ? 1u << 30 : 0u);
+	r.info = full | (eligible ? 1u << 30 : 0u);
+	r.need = need;
 	if (allow_lz && eligible) {
 		uint32_t n = lz_try(lds, L, T, full, base);
 		if (n) {
@@ -1108,9 +1131,11 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	WV_MARK("dec_plane_elems");
 	// ---- element view: lane l owns elements 4l..4l+3, its row is l>>2 ----
 	const U32 row = lane >> 2, q = lane & 3u;
-	U32 info = shfl(hdr | (minv << 8) | (poff << 16), row);
+	// (window offsets fit 16 bits up to bytesoftype 128; beyond, the offset travels on its own)
+	const bool near = T <= 128;
+	U32 info = shfl(hdr | (minv << 8) | (near ? poff << 16 : U32(0u)), row);
 	U32 emask = has_rle ? shfl(rmask, row) : U32(0u);
-	U32 eh = info & 0xFFu, emin = (info >> 8) & 0xFFu, eoff = info >> 16;
+	U32 eh = info & 0xFFu, emin = (info >> 8) & 0xFFu, eoff = near ? info >> 16 : shfl(poff, row);
 	Pred eact = row < U32(lines);
 	Pred e15 = eh == U32(15u), e7 = eh == U32(7u), e6 = eh == U32(6u);
 	Pred erle = e7 | e6;

@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr size_t kMaxT = 64; // largest bytesoftype of the LDS-resident codec (block_codec.h MAX_T)
+constexpr size_t kMaxT = STENOS_MAX_BYTESOFTYPE - 1; // stenos.h:65; above STENOS_K_LDS_MAX_T the kernels of kernels_wide.hip take over
 
 inline bool is_err(size_t r) { return r >= STENOS_LAST_ERROR_CODE; }
 
@@ -188,10 +188,11 @@ struct stenos_context_s {
 	// device state
 	bool probed = false, usable = false;
 	DevBuf in, out;                                  // staging for the host-pointer ABI
-	DevBuf slots, bsize, binfo, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
+	DevBuf slots, bsize, binfo, bneed, boff, sbcsize, sbneed, sbcode, sboff; // workspace of the encode pipeline / decode index
 	DevBuf chain;                                    // fused path: ticket counter + one chained-scan word per superblock
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
+	DevBuf wide;                                     // bytesoftype above 64: scratch of the HBM-resident kernels (kernels_wide.hip)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) unused, [24,32) scan carry, [64,320) override payload
 	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage; // host staging of the strategy layer
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
@@ -220,7 +221,7 @@ struct stenos_context_s {
 	}
 	~stenos_context_s()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide };
 		for (DevBuf* b : all)
 			b->release();
 		HostBuf* host[] = { &h_in, &h_out, &h_blocks, &h_shuf, &h_mid0, &h_mid1, &h_stage };
@@ -287,13 +288,31 @@ size_t plan_frame(const stenos_context_s* ctx, size_t T, size_t bytes, int level
 	return 0;
 }
 
-// What this build cannot do is refused loudly instead of being routed to a CPU path.
+// What this build cannot do is refused loudly instead of being routed to a CPU path (nothing at present: every level and
+// every bytesoftype the reference accepts has a device path).
 size_t check_supported(const stenos_context_s* ctx, size_t T, int level)
 {
 	(void)ctx;
-	if (level >= 1 && T > kMaxT) // the block does not fit the per-wave LDS budget of the codec
-		return STENOS_ERROR_INVALID_PARAMETER;
-	return 0;
+	(void)level;
+	return T > kMaxT ? STENOS_ERROR_INVALID_BYTESOFTYPE : 0;
+}
+// bytesoftype above 64: scratch for the workgroups of kernels_wide.hip, at most 1 GiB (at least one workgroup's worth)
+bool wide_scratch(stenos_context_s* ctx, size_t T, uint64_t units, uint8_t** p, uint64_t* bytes);
+bool wide_scratch(stenos_context_s* ctx, size_t T, uint64_t units, uint8_t** p, uint64_t* bytes)
+{
+	*p = nullptr;
+	*bytes = 0;
+	if (T <= STENOS_K_LDS_MAX_T)
+		return true;
+	const uint64_t stride = stenos_kw_scratch_stride((uint32_t)T);
+	uint64_t groups = ((uint64_t)1 << 30) / stride;
+	groups = groups > units ? units : groups;
+	groups = groups > 2048 ? 2048 : (groups < 1 ? 1 : groups);
+	if (!ctx->wide.ensure((size_t)(groups * stride)))
+		return false;
+	*p = ctx->wide.as<uint8_t>();
+	*bytes = groups * stride;
+	return true;
 }
 // levels >= 2 and bytesoftype 1 go through the strategy layer (block codec on the GPU + zstd on the host)
 inline bool needs_strategy(size_t T, int level) { return level >= 2 || (level == 1 && T == 1); }
@@ -306,7 +325,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 {
 	const uint64_t nblocks = f.nfull + (f.tail ? 1 : 0);
 	const uint32_t stride = stenos_k_slot_stride((uint32_t)T);
-	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
+	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->bneed.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
 	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
 	    !ctx->sboff.ensure((f.nsb + 8) * 8) || !ctx->misc.ensure(4096))
 		return STENOS_ERROR_ALLOC;
@@ -324,6 +343,9 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	j.slots = ctx->slots.as<uint8_t>();
 	j.bsize = ctx->bsize.as<uint32_t>();
 	j.binfo = ctx->binfo.as<uint32_t>();
+	j.bneed = ctx->bneed.as<uint32_t>();
+	if (!wide_scratch(ctx, T, nblocks, &j.wide_scratch, &j.wide_scratch_bytes))
+		return STENOS_ERROR_ALLOC;
 	j.boff = ctx->boff.as<uint32_t>();
 	j.sb_csize = ctx->sbcsize.as<uint32_t>();
 	j.sb_code = ctx->sbcode.as<uint8_t>();
@@ -603,7 +625,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	const uint64_t nblocks = f.nfull + (f.tail ? 1 : 0);
 	const uint32_t stride = stenos_k_slot_stride((uint32_t)T);
 	const size_t tmp_cap = bytes + 4 * (size_t)f.nsb + 64;
-	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
+	if (!ctx->bsize.ensure((nblocks + 1) * 4) || !ctx->binfo.ensure((nblocks + 1) * 4) || !ctx->bneed.ensure((nblocks + 1) * 4) || !ctx->boff.ensure((nblocks + 1) * 4) ||
 	    !ctx->sbcsize.ensure((f.nsb + 1) * 4) || !ctx->sbneed.ensure((f.nsb + 1) * 4) || !ctx->sbcode.ensure(f.nsb + 1) ||
 	    !ctx->sboff.ensure((f.nsb + 8) * 8) || !ctx->misc.ensure(4096) || !ctx->qprod.ensure((f.nsb + 1) * 4) ||
 	    !ctx->slots.ensure((nblocks + 1) * (size_t)stride) || !ctx->tmp1.ensure(tmp_cap))
@@ -617,6 +639,9 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	j.slots = ctx->slots.as<uint8_t>();
 	j.bsize = ctx->bsize.as<uint32_t>();
 	j.binfo = ctx->binfo.as<uint32_t>();
+	j.bneed = ctx->bneed.as<uint32_t>();
+	if (!wide_scratch(ctx, T, nblocks, &j.wide_scratch, &j.wide_scratch_bytes))
+		return STENOS_ERROR_ALLOC;
 	j.boff = ctx->boff.as<uint32_t>();
 	j.sb_csize = ctx->sbcsize.as<uint32_t>();
 	j.sb_code = ctx->sbcode.as<uint8_t>();
@@ -1010,8 +1035,6 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 		return 0;
 	if (!zstd().ok)
 		return STENOS_ERROR_ZSTD_INTERNAL;
-	if (any5 && T > kMaxT)
-		return STENOS_ERROR_INVALID_PARAMETER;
 
 	// The superblocks are inflated by the worker threads into one staging buffer per batch (slot k: 12 spare bytes,
 	// a [1][size:3] header for code 5, the bytes at +16), moved to the device in one copy and finished there.
@@ -1090,6 +1113,8 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 			a.sb_bytes = (uint32_t)fi.sb;
 			a.T = (uint32_t)T;
 			a.status = d_status;
+			if (!wide_scratch(ctx, T, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes))
+				return STENOS_ERROR_ALLOC;
 			if (stenos_k_launch_decode(a, stream) != hipSuccess || hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
 				return STENOS_ERROR_UNDEFINED;
 		}
@@ -1118,8 +1143,6 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 	ctx->job_kind = 0;
 	if (fi.total == 0)
 		return 0;
-	if (T > kMaxT)
-		return STENOS_ERROR_INVALID_PARAMETER;
 	// (a caller's index may be the context's own, from stenos_hip_last_index / stenos_hip_frame_index: only touch it when none is given)
 	if (!ctx->misc.ensure(4096) || (!d_index && !ctx->sboff.ensure((fi.nsb + 2) * 8)))
 		return STENOS_ERROR_ALLOC;
@@ -1141,6 +1164,8 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 	a.sb_bytes = (uint32_t)fi.sb;
 	a.T = (uint32_t)T;
 	a.status = d_status;
+	if (!wide_scratch(ctx, T, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes))
+		return STENOS_ERROR_ALLOC;
 	ctx->mark(2, stream);
 	if (stenos_k_launch_decode(a, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
@@ -1410,7 +1435,7 @@ size_t compress_timed(stenos_context* ctx, const uint8_t* src, size_t T, size_t 
 		const double left = budget - std::chrono::duration<double>(clock::now() - start).count();
 		const double rest = (double)(bytes - pos - n) / rate[0]; // what copying everything behind this slice takes
 		int level = 0;
-		if (top >= 1 && T <= kMaxT && left > 0 && (double)n / rate[1] + rest <= left)
+		if (top >= 1 && left > 0 && (double)n / rate[1] + rest <= left)
 			level = 1;
 		if (level == 1 && top >= 2 && zstd().ok && (double)n / rate[2] + rest <= left * 0.5)
 			level = 2;
@@ -1574,7 +1599,7 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	}
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
-	if (fi.total >= kHostChunkedFrom && !host_codes && bytesoftype <= kMaxT)
+	if (fi.total >= kHostChunkedFrom && !host_codes)
 		return decompress_chunked(ctx, in, bytesoftype, fi, index, out);
 	if (!ctx->in.ensure(size + 64) || !ctx->out.ensure((size_t)fi.total + 64) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
 		return STENOS_ERROR_ALLOC;
@@ -1752,7 +1777,7 @@ size_t stenos_private_decompress_block(stenos_context* ctx, const void* src, siz
 		memcpy(frame.data() + 12, in, 4 + csize);
 		return stenos_decompress_generic(ctx, frame.data(), bytesoftype, frame.size(), dst, dst_size);
 	}
-	if (code != 1 || bytesoftype > kMaxT)
+	if (code != 1)
 		return STENOS_ERROR_INVALID_INPUT;
 	if (dst_size == 0)
 		return 0;
@@ -1777,6 +1802,8 @@ size_t stenos_private_decompress_block(stenos_context* ctx, const void* src, siz
 	a.sb_bytes = (uint32_t)dst_size;
 	a.T = (uint32_t)bytesoftype;
 	a.status = d_status;
+	if (!wide_scratch(ctx, bytesoftype, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes))
+		return STENOS_ERROR_ALLOC;
 	if (stenos_k_launch_decode(a, nullptr) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	uint32_t status = 0;
@@ -1836,7 +1863,14 @@ size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes)
 	// and 37 per superblock (default superblock size).  (A destination below stenos_bound() sends every block through slots.)
 	const size_t arena = stenos_k_fused_supported(T) ? stenos_k_fused_stage_bytes(T, (uint32_t)(sb / bs), nsb) + 2 * (sb / bs + 1) * stenos_k_slot_stride(T)
 							 : nblocks * (size_t)stenos_k_slot_stride(T);
-	return arena + nblocks * 12 + nsb * 37 + 4096;
+	size_t wide = 0; // bytesoftype above 64: the scratch of kernels_wide.hip (wide_scratch())
+	if (T > STENOS_K_LDS_MAX_T) {
+		const size_t stride = stenos_kw_scratch_stride(T);
+		size_t groups = ((size_t)1 << 30) / stride;
+		groups = groups > nblocks ? nblocks : groups;
+		wide = (groups > 2048 ? 2048 : (groups < 1 ? 1 : groups)) * stride;
+	}
+	return arena + wide + nblocks * 16 + nsb * 37 + 4096;
 }
 
 size_t stenos_hip_compress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream)

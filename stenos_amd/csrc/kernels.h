@@ -23,6 +23,8 @@ struct DecodeArgs {
 	uint32_t sb_bytes;
 	uint32_t T;
 	uint32_t* status;
+	uint8_t* wide_scratch = nullptr; // bytesoftype above 64 (kernels_wide.hip), as in FrameJob
+	uint64_t wide_scratch_bytes = 0;
 };
 
 uint32_t stenos_k_cu_count();
@@ -37,6 +39,14 @@ hipError_t stenos_k_launch_resolve(const codec::FrameJob& j, hipStream_t stream)
 hipError_t stenos_k_launch_pack(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
 hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream);
 hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream);
+
+// kernels_wide.hip: bytesoftype above codec::MAX_T of the LDS-resident kernels (the launchers above forward to these)
+constexpr uint32_t STENOS_K_LDS_MAX_T = 64;
+size_t stenos_kw_scratch_stride(uint32_t T);
+hipError_t stenos_kw_launch_encode(const codec::FrameJob& j, uint64_t b_begin, uint64_t b_end, hipStream_t stream);
+hipError_t stenos_kw_launch_plan(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
+hipError_t stenos_kw_launch_resolve(const codec::FrameJob& j, hipStream_t stream);
+hipError_t stenos_kw_launch_decode(const DecodeArgs& a, hipStream_t stream);
 
 // byte_kernels.hip
 hipError_t stenos_k_launch_shuffle(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t bytes, bool inverse, hipStream_t stream);

@@ -29,7 +29,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 template <uint32_t TT>
 __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ src, uint64_t b_begin, uint64_t b_end, uint64_t nfull, uint32_t tail_bytes, uint32_t Trt,
 						    uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ bsize,
-						    uint32_t* __restrict__ binfo)
+						    uint32_t* __restrict__ binfo, uint32_t* __restrict__ bneed)
 {
 	const uint32_t T = TT ? TT : Trt;
 	const Layout L = make_layout(T, true);
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64) void encode_blocks(const uint8_t* __restrict__ 
 		if (threadIdx.x == 0) {
 			bsize[b] = r.size;
 			binfo[b] = r.info;
+			bneed[b] = r.need;
 		}
 	}
 }
@@ -397,7 +398,7 @@ static hipError_t launch_encode_t(const FrameJob& j, uint64_t b_begin, uint64_t 
 	// 8 GiB of int32): the dispatcher staggers the waves, a resident grid runs them in phase.
 	const uint32_t grid = (uint32_t)(b_end - b_begin);
 	hipLaunchKernelGGL(encode_blocks<TT>, dim3(grid), dim3(64), lds, stream, j.src, b_begin, b_end, j.nfull, j.tail_bytes, j.T, j.slots, j.slot_stride,
-			   j.bsize, j.binfo);
+			   j.bsize, j.binfo, j.bneed);
 	return hipGetLastError();
 }
 
@@ -437,7 +438,7 @@ hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t
 	}
 }
 // the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)
-bool stenos_k_fused_supported(uint32_t T) { return FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 64 <= 160u * 1024u; }
+bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 64 <= 160u * 1024u; }
 // encoder workgroups of the fused kernel: as many as stay resident (they take superblocks until none is left)
 uint32_t stenos_k_fused_groups(uint64_t nsb)
 {
@@ -454,6 +455,8 @@ hipError_t stenos_k_launch_encode(const FrameJob& j, uint64_t b_begin, uint64_t 
 {
 	if (b_end <= b_begin)
 		return hipSuccess;
+	if (j.T > STENOS_K_LDS_MAX_T)
+		return stenos_kw_launch_encode(j, b_begin, b_end, stream);
 	switch (j.T) {
 		case 2: return launch_encode_t<2>(j, b_begin, b_end, stream);
 		case 4: return launch_encode_t<4>(j, b_begin, b_end, stream);
@@ -467,6 +470,8 @@ hipError_t stenos_k_launch_plan(const FrameJob& j, uint64_t s_begin, uint64_t s_
 {
 	if (s_end <= s_begin)
 		return hipSuccess;
+	if (j.T > STENOS_K_LDS_MAX_T)
+		return stenos_kw_launch_plan(j, s_begin, s_end, stream);
 	// the replay inside the plan (fixed-capacity mode) re-encodes blocks and needs the encoder's LDS
 	const size_t lds = j.fixed_capacity ? stenos_k_encode_lds_bytes(j.T) : 0;
 	if (lds) {
@@ -488,6 +493,8 @@ hipError_t stenos_k_launch_scan(const FrameJob& j, uint64_t s_begin, uint64_t s_
 
 hipError_t stenos_k_launch_resolve(const FrameJob& j, hipStream_t stream)
 {
+	if (j.T > STENOS_K_LDS_MAX_T)
+		return stenos_kw_launch_resolve(j, stream);
 	const size_t lds = stenos_k_encode_lds_bytes(j.T);
 	hipError_t e = hipFuncSetAttribute((const void*)resolve_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
@@ -523,6 +530,8 @@ static hipError_t launch_decode_t(const DecodeArgs& a, hipStream_t stream)
 
 hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream)
 {
+	if (a.T > STENOS_K_LDS_MAX_T)
+		return stenos_kw_launch_decode(a, stream);
 	switch (a.T) {
 		case 2: return launch_decode_t<2>(a, stream);
 		case 4: return launch_decode_t<4>(a, stream);

@@ -27,6 +27,7 @@ struct FrameJob {
 	uint8_t* slots;
 	uint32_t* bsize;   // encoded size of every block (tail block last)
 	uint32_t* binfo;   // BlockInfo::info of every block
+	uint32_t* bneed;   // BlockInfo::need of every block
 	uint32_t* boff;    // offset of every block inside its superblock payload
 	uint32_t* sb_csize;
 	uint8_t* sb_code;
@@ -56,6 +57,9 @@ struct FrameJob {
 	// and qprod[s] receives the bytes produced when the reference checks its target ratio (block_compress.h:1267)
 	uint32_t fixed_capacity;
 	uint32_t* qprod;
+	// bytesoftype above 64 (kernels_wide.hip): device scratch the workgroups share out, stenos_kw_scratch_stride(T) bytes each
+	uint8_t* wide_scratch;
+	uint64_t wide_scratch_bytes;
 };
 
 WV_HD uint32_t superblock_bytes(const FrameJob& j, uint64_t s)
@@ -72,9 +76,9 @@ WV_HD uint32_t superblock_blocks(const FrameJob& j, uint64_t s) // full blocks +
 
 // capacity a block needs, counted from the start of the payload, for its fast-path encoding to be
 // what the reference produces; a = offset of the block in the payload
-WV_FN U32 block_requirement(const U32& a, const U32& info, const Pred& is_tail, uint32_t T)
+WV_FN U32 block_requirement(const U32& a, const U32& info, const U32& need, const Pred& is_tail, uint32_t T)
 {
-	U32 full = info & 0x7FFFu, need = (info >> 15) & 0x7FFFu;
+	U32 full = info & 0x3FFFFFFFu;
 	Pred lz = ((info >> 31) & 1u) == U32(1u);
 	U32 lzreq = a + U32(header_bytes(T)) + full + U32(8u * T + 3u); // C > d + full + 8T + 2
 	return sel(!is_tail & lz, lzreq, a + need);
@@ -96,11 +100,12 @@ WV_FN void plan_superblock(Lds lds, const Layout& L, const FrameJob& j, uint64_t
 			Pred p = i < U32(count);
 			U32 sz = gld32((const uint8_t*)(j.bsize + first), i * 4u, p);
 			U32 info = gld32((const uint8_t*)(j.binfo + first), i * 4u, p);
+			U32 bneed = gld32((const uint8_t*)(j.bneed + first), i * 4u, p);
 			U32 incl = wave_incl_scan(sz);
 			U32 a = U32(run) + incl - sz;
 			gst32((uint8_t*)(j.boff + first), i * 4u, a, p);
 			Pred is_tail = pred_all(has_tail) & (i == U32(count - 1));
-			uint32_t m = wave_max(sel(p, block_requirement(a, info, is_tail, j.T), U32(0u)));
+			uint32_t m = wave_max(sel(p, block_requirement(a, info, bneed, is_tail, j.T), U32(0u)));
 			need = m > need ? m : need;
 			run += readlane(incl, 63);
 		}
@@ -165,6 +170,7 @@ WV_FN bool replay_superblock(Lds lds, const Layout& L, const FrameJob& j, uint64
 	for (uint32_t i = 0; i < count; ++i) {
 		const uint64_t b = first + i;
 		uint32_t info = gload_uniform(j.binfo + b);
+		uint32_t bneed = gload_uniform(j.bneed + b);
 		uint32_t size = gload_uniform(j.bsize + b);
 		const bool is_tail = has_tail && i == count - 1;
 		if (!is_tail && info_lz_ok(info) && !(C > a + hs + info_full(info) + 8 * T + 2)) {
@@ -172,11 +178,13 @@ WV_FN bool replay_superblock(Lds lds, const Layout& L, const FrameJob& j, uint64
 			BlockInfo r = encode_block_job(lds, L, T, j.src + b * (uint64_t)bs, j.slots + b * (uint64_t)j.slot_stride, false);
 			size = r.size;
 			info = r.info;
+			bneed = r.need;
 			gstore_uniform(j.bsize + b, size);
 			gstore_uniform(j.binfo + b, info);
+			gstore_uniform(j.bneed + b, bneed);
 		}
 		const bool kept_lz = !is_tail && info_lz_ok(info);
-		if (!kept_lz && a + info_need(info) > C) // one of the reference's dst_end tests fails
+		if (!kept_lz && a + bneed > C) // one of the reference's dst_end tests fails
 			return false;
 		gstore_uniform(j.boff + b, (uint32_t)a);
 		a += size;

@@ -370,7 +370,8 @@ WV_FN BlockInfo encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint
 	store_block(slot, lds, L.out, (size + 15u) & ~15u);
 	BlockInfo r;
 	r.size = size;
-	r.info = need << 15;
+	r.info = 0;
+	r.need = need;
 	return r;
 }
 

@@ -584,6 +584,18 @@ WV_FN void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef STENOS_WIDE
+// kernels_wide.hip: the wave's scratch lies in HBM.  Its OR-ed images are built by atomics, which execute in the L2, so
+// the reads go there too instead of trusting a line of the vector L1.
+WV_FN uint32_t wide_ld32(const uint8_t* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_FN U32 lds_ld8(Lds m, U32 a) { return __hip_atomic_load(m + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_FN U32 lds_ld32(Lds m, U32 a) { return wide_ld32(m + (a & ~3u)); }
+WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
+{
+	lo = wide_ld32(m + (a & ~3u));
+	hi = wide_ld32(m + (a & ~3u) + 4);
+}
+#else
 WV_FN U32 lds_ld8(Lds m, U32 a) { return m[a]; }
 WV_FN U32 lds_ld32(Lds m, U32 a) { return *(const uint32_t*)(m + (a & ~3u)); }
 WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
@@ -591,6 +603,7 @@ WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
 	lo = *(const uint32_t*)(m + (a & ~3u));
 	hi = *(const uint32_t*)(m + (a & ~3u) + 4);
 }
+#endif
 WV_FN void lds_st32(Lds m, U32 a, U32 v, Pred p)
 {
 	if (p) *(uint32_t*)(m + (a & ~3u)) = v;
@@ -673,8 +686,12 @@ WV_FN void gmin32(uint32_t* p, uint32_t v)
 }
 WV_FN U128 lds_ld128(Lds m, U32 a)
 {
+#ifdef STENOS_WIDE
+	U128 r = { wide_ld32(m + a), wide_ld32(m + a + 4), wide_ld32(m + a + 8), wide_ld32(m + a + 12) };
+#else
 	uint4 v = *(const uint4*)(m + a);
 	U128 r = { v.x, v.y, v.z, v.w };
+#endif
 	return r;
 }
 WV_FN void lds_st128(Lds m, U32 a, const U128& v, Pred p)

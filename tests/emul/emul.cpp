@@ -101,7 +101,7 @@ size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last fr
 size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, int level)
 {
 	const size_t ERR_DST = (size_t)-6, ERR_PARAM = (size_t)-9;
-	if (T < 2 || T > MAX_T || level < 0 || level > 1)
+	if (T < 2 || T >= 65535 || level < 0 || level > 1)
 		return ERR_PARAM;
 	const size_t bs = 256 * T;
 	size_t sb = bs > 131072 ? bs : (131072 / bs) * bs;
@@ -135,7 +135,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	uint8_t* slots = nullptr;
 	if (posix_memalign((void**)&slots, 64, (nblocks + 1) * (size_t)j.slot_stride + 64))
 		return (size_t)-3;
-	std::vector<uint32_t> bsize(nblocks + 1), binfo(nblocks + 1), boff(nblocks + 1), sbcsize(j.nsb + 1), sbneed(j.nsb + 1);
+	std::vector<uint32_t> bsize(nblocks + 1), binfo(nblocks + 1), bneed(nblocks + 1), boff(nblocks + 1), sbcsize(j.nsb + 1), sbneed(j.nsb + 1);
 	std::vector<uint8_t> sbcode(j.nsb + 1), frame(dst_size + 64, 0xA5), payload(256);
 	std::vector<uint64_t> sboff(j.nsb + 2);
 	uint64_t total = 0;
@@ -146,6 +146,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 	j.slots = slots;
 	j.bsize = bsize.data();
 	j.binfo = binfo.data();
+	j.bneed = bneed.data();
 	j.boff = boff.data();
 	j.sb_csize = sbcsize.data();
 	j.sb_code = sbcode.data();
@@ -207,6 +208,7 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 						 : encode_tail_job(lds, L, j.T, src + j.nfull * bs, j.tail_bytes, slots + j.nfull * (size_t)j.slot_stride);
 			bsize[b] = r.size;
 			binfo[b] = r.info;
+			bneed[b] = r.need;
 		}
 	for (uint64_t s = s_fused; s < j.nsb; ++s) // plan_superblocks
 		plan_superblock(lds, L, j, s);

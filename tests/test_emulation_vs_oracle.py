@@ -230,3 +230,62 @@ def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T):
             r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
             assert emul.emul_last_fused() > 0
             assert r2 == r1 and np.array_equal(out[:r2], f1), (pattern, cut)
+
+
+@pytest.mark.parametrize("T", [65, 100, 128, 132, 508, 512, 516, 1000, 4100])
+def test_wide_types_block_codec(oracle, emul, T):
+    """bytesoftype above 64 (kernels_wide.hip runs this same source with its scratch in HBM): planes are handled 64 at a
+    time (plane_offsets, type nibbles), the mini-LZ is tried up to bytesoftype 512 only (lz_compress.h:281-283, 15-bit
+    distances) and a block no longer fits 16-bit window offsets."""
+    for kind in ["rand", "same", "walk", "dict16", "runs", "burst", "mixed", "lzmix", "sorted"]:
+        for n in (256, 300, 515):
+            data = generate(kind, T, n, 42 + n)
+            nb = data.nbytes
+            ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+            out = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r2 = emul.emul_block_compress(np_ptr(data), T, nb, np_ptr(out), 1)
+            assert r1 == r2 and np.array_equal(ref[:r1], out[:r1]), (kind, n)
+            dec = np.zeros(nb + 64, dtype=np.uint8)
+            r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), 5)
+            assert r3 == nb and np.array_equal(dec[:nb], data) and not dec[nb:].any(), (kind, n)
+
+
+def test_widest_type_block_codec(oracle, emul):
+    T = 65534  # stenos.h:65: the largest bytesoftype the reference accepts; plane offsets reach 280 * T
+    for kind, n in (("mixed", 300), ("walk", 515), ("rand", 256)):
+        data = generate(kind, T, n, 5)
+        nb = data.nbytes
+        ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+        r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+        out = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+        r2 = emul.emul_block_compress(np_ptr(data), T, nb, np_ptr(out), 1)
+        assert r1 == r2 and np.array_equal(ref[:r1], out[:r1]), kind
+        dec = np.zeros(nb + 64, dtype=np.uint8)
+        r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), 0)
+        assert r3 == nb and np.array_equal(dec[:nb], data), kind
+
+
+@pytest.mark.parametrize("T", [65, 100, 512, 516, 700])
+def test_wide_types_frame_pipeline_and_capacity_rules(oracle, emul, T):
+    """encode_blocks / plan / scan / resolve / pack for bytesoftype above 64 against the oracle's serial path, with roomy
+    and tight destinations (superblocks of a few blocks up to 512, of one block above)."""
+    from _libs import oracle_compress
+    from stenos_amd.datagen import splitmix64
+
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    bs = 256 * T
+    per = (131072 // bs * 256) if bs <= 131072 else 256
+    for kind in ["rand", "walk", "dict16", "mixed", "lzmix", "burst"]:
+        for n in [1, 100, 256, 257, per + 1, 2 * per + 300]:
+            data = generate(kind, T, n, 77 + n)
+            bound = oracle.so_bound(data.nbytes)
+            caps = [bound + 5000, bound] + [max(0, bound - int(x)) for x in (splitmix64(n, 3) % np.uint64(max(10, data.nbytes // 3)))]
+            for cap in caps:
+                r1, f1 = oracle_compress(oracle, data, T, 1, cap)
+                out = np.zeros(cap + 64, dtype=np.uint8)
+                r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
+                assert has_error(r1) == has_error(r2), (kind, n, cap, hex(r1), hex(r2))
+                if not has_error(r1):
+                    assert r1 == r2 and np.array_equal(f1, out[:r2]), (kind, n, cap)

@@ -250,12 +250,60 @@ def test_chunked_host_calls(lib, oracle, T, kind, n, shift):
     lib.stenos_destroy_context(c)
 
 
-def test_unsupported_requests_fail_loudly(lib):
+@pytest.mark.parametrize("T", [65, 100, 128, 132, 512, 516, 1000, 20001, 65534])
+def test_wide_types(lib, oracle, ref_det, T):
+    """bytesoftype above 64 (the reference accepts up to 65534, stenos.h:65): kernels_wide.hip runs the block codec with its
+    scratch in HBM.  Same frames as the oracle, tight destinations included, and the same bytes back; the compiled
+    reference decodes them."""
     c = lib.stenos_make_context()
-    out = np.zeros(64, dtype=np.uint8)
-    wide = generate("rand", 65, 3000, 1)  # bytesoftype > 64 at level >= 1: block does not fit the per-wave LDS budget
-    assert has_error(lib.stenos_compress_generic(c, np_ptr(wide), 65, wide.nbytes, np_ptr(np.zeros(lib.stenos_bound(wide.nbytes), dtype=np.uint8)),
-                                                 lib.stenos_bound(wide.nbytes)))
+    bs = 256 * T
+    per = (131072 // bs * 256) if bs <= 131072 else 256
+    kinds = ["mixed", "walk", "rand", "lzmix", "dict16", "burst"] if T <= 1000 else ["mixed", "walk"]
+    for kind in kinds:
+        for n in ([100, 256, 2 * per + 300] if T <= 1000 else [2 * 256 + 77]):
+            data = generate(kind, T, n, 31 + n)
+            r1, ref = oracle_compress(oracle, data, T, 1)
+            r2, frame = gpu_compress(lib, c, data, T, 1)
+            assert r1 == r2 and np.array_equal(ref, frame), (kind, n)
+            r3, back = gpu_decompress(lib, c, frame, T, data.nbytes)
+            assert r3 == data.nbytes and np.array_equal(back, data), (kind, n)
+            if T <= 1000:
+                for cap in (r1, r1 - 1, max(0, r1 - bs // 3)):
+                    r4, again = gpu_compress(lib, c, data, T, 1, dst_size=cap)
+                    r5, exp = oracle_compress(oracle, data, T, 1, dst_size=cap)
+                    assert has_error(r4) == has_error(r5), (kind, n, cap)
+                    if not has_error(r4):
+                        assert r4 == r5 and np.array_equal(again, exp), (kind, n, cap)
+            # (the reference cannot decode exact multiples of the superblock size, and its partial-block encoder overruns
+            # its heap buffer from bytesoftype 19 on, block_compress.h:321, 966-968: whole blocks only, decode only)
+            if n % 256 == 0 and data.nbytes % (per * T):
+                out = np.zeros(data.nbytes + 65536, dtype=np.uint8)
+                assert ref_det.stenos_decompress(np_ptr(frame), T, r2, np_ptr(out), data.nbytes) == data.nbytes
+                assert np.array_equal(out[: data.nbytes], data), (kind, n)
+    lib.stenos_destroy_context(c)
+
+
+@pytest.mark.parametrize("T,level", [(72, 2), (100, 3), (300, 5)])
+def test_wide_types_through_the_strategy_layer(lib, ref_det, T, level):
+    """levels >= 2 use the same block kernels for their BLOCK / BLOCK_ZSTD candidates (stenos.cpp:546-604)."""
+    c = lib.stenos_make_context()
+    data = generate("mixed", T, 768, 3)  # whole blocks: see test_wide_types
+    r, frame = gpu_compress(lib, c, data, T, level)
+    assert not has_error(r)
+    r3, back = gpu_decompress(lib, c, frame, T, data.nbytes)
+    assert r3 == data.nbytes and np.array_equal(back, data)
+    exp = np.zeros(lib.stenos_bound(data.nbytes), dtype=np.uint8)
+    r2 = ref_det.stenos_compress(np_ptr(data), T, data.nbytes, np_ptr(exp), exp.nbytes, level)
+    assert r2 == r and np.array_equal(exp[:r], frame)
+    lib.stenos_destroy_context(c)
+
+
+def test_invalid_bytesoftype_is_refused(lib):
+    c = lib.stenos_make_context()
+    data = np.zeros(70000, dtype=np.uint8)
+    out = np.zeros(lib.stenos_bound(data.nbytes), dtype=np.uint8)
+    for T in (0, 65535, 70000):  # stenos.cpp:119-120
+        assert has_error(lib.stenos_compress_generic(c, np_ptr(data), T, data.nbytes, np_ptr(out), out.nbytes))
     assert not out.any()
     lib.stenos_destroy_context(c)
 
