@@ -1072,8 +1072,10 @@ WV_FN U32 expand_literals(const U32& lits, const U32& f)
 }
 
 // Decode one NORMAL / NORMAL_RLE plane whose bytes start at window offset `cur` (at most `avail`
-// valid bytes).  Writes rows [0, lines) of plane j into the image.  Returns bytes consumed or DEC_ERROR.
-WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, uint32_t avail, uint32_t lines)
+// valid bytes).  Writes rows [0, lines) of plane j into the image or, with `keep`, hands the lane's plane word back instead.
+// Returns bytes consumed or DEC_ERROR.
+WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, uint32_t avail, uint32_t lines,
+			    U32* keep = nullptr)
 {
 	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
@@ -1194,7 +1196,10 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		outw = chain_apply(A, Bw, cin);
 	}
 	WV_MARK("dec_plane_store");
-	store_plane_word(lds, L.img, T, j, outw, eact);
+	if (keep)
+		*keep = outw;
+	else
+		store_plane_word(lds, L.img, T, j, outw, eact);
 	WV_MARK("dec_plane_end");
 	return psize;
 }
@@ -1273,10 +1278,75 @@ WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, 
 	return p - cur;
 }
 
+// A full block of bytesoftype 2, 4 or 8 made of planes (not COPY, not LZ), straight to HBM: the lane's word of every plane
+// stays in a register, three (bytesoftype 2: one) v_perm_b32 per element turn them into the lane's four elements and one
+// or two 16-byte stores write them.  No byte stores into an element-major image (stride 4*T between the lanes: LDS bank
+// conflicts), no image to read back.  g: where the block goes, aligned to 4*T bytes.  head: the type nibbles.
+template <uint32_t T>
+WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint32_t avail, uint32_t head, uint8_t* g)
+{
+	const U32 lane = lane_id_plain();
+	Lds win = lds + L.win;
+	uint32_t p = cur + header_bytes(T), bad = 0;
+	const uint32_t end = cur + avail;
+	U32 w[T];
+#ifndef WV_HOST_EMULATION
+#pragma unroll
+#endif
+	for (uint32_t j = 0; j < T; ++j) {
+		const uint32_t type = (head >> (4 * j)) & 15;
+		w[j] = U32(0u);
+		if (type >= PLANE_NORMAL) {
+			if (type <= PLANE_NORMAL_RLE)
+				p += decode_plane(lds, L, T, j, type, p, end - p, 16, &w[j]);
+			else
+				bad = 1; // (:1854-1855)
+		}
+		else if (type == PLANE_SAME) { // (:1567-1583)
+			w[j] = bytes_splat(lds_ld8(win, U32(p)));
+			p += 1;
+		}
+		else { // RAW (:1553-1565)
+			w[j] = lds_ld32_unaligned(win, U32(p) + lane * 4u);
+			p += 256;
+		}
+	}
+	if (bad || p > end)
+		return DEC_ERROR;
+	if (T == 2)
+		gst64(g, lane * 8u, perm_bytes(w[1], w[0], 0x05010400u), perm_bytes(w[1], w[0], 0x07030602u), pred_all(true));
+	else {
+		U32 e[T / 4 ? T / 4 : 1][4]; // e[h][i]: bytes 4h .. 4h+3 of the lane's element i
+		for (uint32_t h = 0; h < T / 4; ++h) {
+			const U32 a01 = perm_bytes(w[4 * h + 1], w[4 * h], 0x05010400u), a23 = perm_bytes(w[4 * h + 3], w[4 * h + 2], 0x05010400u); // elements 0 and 1
+			const U32 b01 = perm_bytes(w[4 * h + 1], w[4 * h], 0x07030602u), b23 = perm_bytes(w[4 * h + 3], w[4 * h + 2], 0x07030602u); // elements 2 and 3
+			e[h][0] = perm_bytes(a23, a01, 0x05040100u);
+			e[h][1] = perm_bytes(a23, a01, 0x07060302u);
+			e[h][2] = perm_bytes(b23, b01, 0x05040100u);
+			e[h][3] = perm_bytes(b23, b01, 0x07060302u);
+		}
+		U128 v;
+		if (T == 4) {
+			v.x = e[0][0], v.y = e[0][1], v.z = e[0][2], v.w = e[0][3];
+			gst128(g, lane * 16u, v, pred_all(true));
+		}
+		else {
+			v.x = e[0][0], v.y = e[T / 4 - 1][0], v.z = e[0][1], v.w = e[T / 4 - 1][1];
+			gst128(g, lane * 32u, v, pred_all(true));
+			v.x = e[0][2], v.y = e[T / 4 - 1][2], v.z = e[0][3], v.w = e[T / 4 - 1][3];
+			gst128(g, lane * 32u + 16u, v, pred_all(true));
+		}
+	}
+	return p - cur;
+}
+
 // Decode `lines` rows (16 = a full block) of the block whose encoding starts at window offset cur.
 // full: a full block (may be COPY / LZ, planes may be RAW / NORMAL_RLE).
+// g (optional, full blocks of bytesoftype 2, 4, 8 known at compile time): the block's place in HBM, suitably aligned; a
+// block made of planes is then written there directly and *direct set, anything else lands in the image as usual.
 // Returns bytes consumed or DEC_ERROR.
-WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail, uint32_t lines, bool full)
+WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail, uint32_t lines, bool full, uint8_t* g = nullptr,
+			    bool* direct = nullptr)
 {
 	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
@@ -1301,6 +1371,14 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 			return DEC_ERROR;
 		uint32_t n = lz_decode(lds, L, T, cur + 1, avail - 1);
 		return n == DEC_ERROR ? DEC_ERROR : n + 1;
+	}
+	if (g && full) {
+		*direct = true;
+		if (T == 2)
+			return decode_planes_to<2>(lds, L, cur, avail, head, g);
+		if (T == 4)
+			return decode_planes_to<4>(lds, L, cur, avail, head, g);
+		return decode_planes_to<8>(lds, L, cur, avail, head, g);
 	}
 	uint32_t p = cur + hs;
 	const uint32_t end = cur + avail;

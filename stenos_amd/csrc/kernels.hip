@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 	uint8_t* out = a.dst + begin;
 	if (code == 1) {
 		const DecLayout L = make_dec_layout(T);
-		uint32_t r = decode_superblock(g_lds, L, T, payload, csize, out, dsize);
+		uint32_t r = decode_superblock(g_lds, L, T, payload, csize, out, dsize, TT != 0);
 		if (r == DEC_ERROR && threadIdx.x == 0)
 			atomicOr(a.status, DECODE_STATUS_INVALID);
 	}

@@ -398,7 +398,8 @@ WV_HD DecLayout make_dec_layout(uint32_t T)
 
 // Decode the payload of one BLOCK superblock (code 1): `csize` compressed bytes at src -> `dsize`
 // bytes at dst.  Returns dsize, or DEC_ERROR on a malformed / truncated stream.
-WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t dsize)
+// regs: T is 2, 4 or 8 and known at compile time: blocks made of planes go to HBM from registers (decode_planes_to)
+WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t dsize, bool regs = false)
 {
 	const U32 lane = lane_id_plain();
 	const uint32_t bs = 256 * T, hs = header_bytes(T);
@@ -412,6 +413,7 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 	const uint8_t* abase = src - mis;
 	uint32_t wstart = 0, wfill = 0, wend = 0; // window holds abase[wstart, wend), wend = wstart + wfill
 	uint32_t consumed = 0;          // payload bytes consumed so far
+	const bool to_hbm = regs && (((uintptr_t)dst) & 15u) == 0;
 
 	auto ensure = [&](uint32_t need) {
 		// make payload bytes [consumed, consumed + need) resident (need already clipped to the payload)
@@ -451,12 +453,15 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 		uint32_t need = left < max_block_bytes(T) ? left : max_block_bytes(T);
 		ensure(need);
 		WV_MARK("dec_block");
-		uint32_t n = decode_block(lds, L, T, consumed + mis - wstart, need, 16, true);
+		bool direct = false;
+		uint32_t n = decode_block(lds, L, T, consumed + mis - wstart, need, 16, true, to_hbm ? dst + (size_t)b * bs : nullptr, &direct);
 		if (n == DEC_ERROR)
 			return DEC_ERROR;
 		WV_MARK("dec_block_store");
-		store_block(dst + (size_t)b * bs, lds, L.img, bs);
-		wave_sync();
+		if (!direct) {
+			store_block(dst + (size_t)b * bs, lds, L.img, bs);
+			wave_sync();
+		}
 		consumed += n;
 	}
 	const uint32_t tail = dsize - nblocks * bs;

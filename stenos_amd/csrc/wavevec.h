@@ -395,6 +395,14 @@ WV_FN void gst32(uint8_t* g, const U32& off, const U32& v, const Pred& p)
 	for (int i = 0; i < WAVE; ++i)
 		if (p.l[i]) memcpy(g + off.l[i], &v.l[i], 4);
 }
+WV_FN void gst64(uint8_t* g, const U32& off, const U32& lo, const U32& hi, const Pred& p)
+{
+	for (int i = 0; i < WAVE; ++i)
+		if (p.l[i]) {
+			memcpy(g + off.l[i], &lo.l[i], 4);
+			memcpy(g + off.l[i] + 4, &hi.l[i], 4);
+		}
+}
 WV_FN void gst128(uint8_t* g, const U32& off, const U128& v, const Pred& p)
 {
 	for (int i = 0; i < WAVE; ++i)
@@ -659,6 +667,10 @@ WV_FN void gst8(uint8_t* g, U32 off, U32 v, Pred p)
 WV_FN void gst32(uint8_t* g, U32 off, U32 v, Pred p)
 {
 	if (p) *(uint32_t*)(g + off) = v;
+}
+WV_FN void gst64(uint8_t* g, U32 off, U32 lo, U32 hi, Pred p)
+{
+	if (p) *(uint2*)(g + off) = make_uint2(lo, hi);
 }
 WV_FN void gst128(uint8_t* g, U32 off, const U128& v, Pred p)
 {

@@ -24,6 +24,8 @@ static uint8_t* alloc_lds(uint32_t bytes)
 	return (uint8_t*)p;
 }
 
+static int g_dec_regs = 1; // decode_superblock's register path for bytesoftype 2, 4, 8 (what the templated kernels use)
+
 extern "C" {
 
 // payload of one BLOCK superblock with unlimited capacity (block_compress.h:1099-1302)
@@ -69,7 +71,7 @@ size_t emul_block_decompress(const uint8_t* src, size_t csize, size_t T, size_t 
 		return (size_t)-3;
 	memset(in, 0xEE, csize + 128);
 	memcpy(in + 16 + misalign, src, csize);
-	uint32_t r = decode_superblock(lds, L, (uint32_t)T, in + 16 + misalign, (uint32_t)csize, out, (uint32_t)dsize);
+	uint32_t r = decode_superblock(lds, L, (uint32_t)T, in + 16 + misalign, (uint32_t)csize, out, (uint32_t)dsize, g_dec_regs && (T == 2 || T == 4 || T == 8));
 	if (r != DEC_ERROR)
 		memcpy(dst, out, dsize);
 	free(in);
@@ -82,6 +84,7 @@ size_t emul_block_decompress(const uint8_t* src, size_t csize, size_t T, size_t 
 // resolve_frame, host zstd for a tiny last superblock, pack_frame), one "workgroup" after the other.
 
 static int g_fused = 1;
+void emul_set_dec_regs(int on) { g_dec_regs = on; }
 static int g_slots = 1; // 0: the plane-group loop of encode_run also for bytesoftype 2 and 4 (the fused kernel's GROUPS twin)
 void emul_set_slots(int on) { g_slots = on; }
 // decoder LDS layout (superblock_codec.h): out = { window offset, image offset, total, window capacity, reach of one block }

@@ -30,6 +30,8 @@ def emul():
     lib.emul_set_fused.argtypes = [c_int]
     lib.emul_set_slots.restype = None
     lib.emul_set_slots.argtypes = [c_int]
+    lib.emul_set_dec_regs.restype = None
+    lib.emul_set_dec_regs.argtypes = [c_int]
     return lib
 
 
@@ -289,3 +291,21 @@ def test_wide_types_frame_pipeline_and_capacity_rules(oracle, emul, T):
                 assert has_error(r1) == has_error(r2), (kind, n, cap, hex(r1), hex(r2))
                 if not has_error(r1):
                     assert r1 == r2 and np.array_equal(f1, out[:r2]), (kind, n, cap)
+
+
+@pytest.mark.parametrize("T", [2, 4, 8])
+def test_decoder_image_path_for_small_types(oracle, emul, T):
+    """The kernels instantiated for bytesoftype 2, 4 and 8 write blocks made of planes to HBM from registers
+    (decode_planes_to); a destination that is not 16-byte aligned sends them through the LDS image like every other
+    bytesoftype.  Same bytes either way."""
+    for kind in KINDS:
+        data = generate(kind, T, 1280 + 77, 11)
+        nb = data.nbytes
+        ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+        r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+        for regs in (0, 1):
+            emul.emul_set_dec_regs(regs)
+            dec = np.zeros(nb + 64, dtype=np.uint8)
+            r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), 3)
+            assert r3 == nb and np.array_equal(dec[:nb], data) and not dec[nb:].any(), (kind, regs)
+    emul.emul_set_dec_regs(1)
