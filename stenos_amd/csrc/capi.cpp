@@ -1209,11 +1209,12 @@ class Uploader {
 	std::atomic<bool> cancel{ false };
 
 public:
-	void start(size_t chunks, std::function<bool(size_t)> upload)
+	bool start(size_t chunks, std::function<bool(size_t)> upload) // false: no thread to be had (the caller takes the single pass)
 	{
 		int device = 0;
 		(void)hipGetDevice(&device);
-		th = std::thread([this, chunks, upload, device] {
+		try {
+			th = std::thread([this, chunks, upload, device] {
 			bool ok = hipSetDevice(device) == hipSuccess;
 			for (size_t k = 0; k < chunks; ++k) {
 				ok = ok && !cancel.load() && upload(k);
@@ -1224,7 +1225,12 @@ public:
 				if (!ok)
 					break;
 			}
-		});
+			});
+		}
+		catch (...) {
+			return false;
+		}
+		return true;
 	}
 	bool wait_for(size_t k)
 	{
@@ -1258,10 +1264,11 @@ size_t compress_chunked(stenos_context_s* ctx, const uint8_t* src, size_t T, siz
 	uint8_t* d_in = ctx->in.as<uint8_t>();
 	hipStream_t up_stream = ctx->up_stream, stream = ctx->main_stream;
 	Uploader up;
-	up.start(chunks, [=](size_t k) {
-		const size_t begin = k * chunk, n = bytes - begin < chunk ? bytes - begin : chunk;
-		return hipMemcpyAsync(d_in + begin, src + begin, n, hipMemcpyHostToDevice, up_stream) == hipSuccess && hipStreamSynchronize(up_stream) == hipSuccess;
-	});
+	if (!up.start(chunks, [=](size_t k) {
+		    const size_t begin = k * chunk, n = bytes - begin < chunk ? bytes - begin : chunk;
+		    return hipMemcpyAsync(d_in + begin, src + begin, n, hipMemcpyHostToDevice, up_stream) == hipSuccess && hipStreamSynchronize(up_stream) == hipSuccess;
+	    }))
+		return STENOS_ERROR_ALLOC;
 	out[0] = (uint8_t)f.shift;
 	put_le(out + 1, bytes, 7);
 	if (f.header == 12)
@@ -1315,14 +1322,15 @@ size_t decompress_chunked(stenos_context_s* ctx, const uint8_t* in, size_t T, co
 	const uint64_t nsb = fi.nsb;
 	auto chunk_frame = [=](size_t k) { return d_in + idx[k * per] + 16 * (k + 1) - H; };
 	Uploader up;
-	up.start(chunks, [=](size_t k) {
-		const uint64_t s0 = k * per, s1 = s0 + per < nsb ? s0 + per : nsb;
-		uint8_t* d = chunk_frame(k);
-		return hipMemcpyAsync(d, hdrp + 12 * k, H, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
-		       hipMemcpyAsync(d + H, in + idx[s0], idx[s1] - idx[s0], hipMemcpyHostToDevice, up_stream) == hipSuccess &&
-		       hipMemcpyAsync(d_rel + s0 + k, relp + s0 + k, (s1 - s0 + 1) * 8, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
-		       hipStreamSynchronize(up_stream) == hipSuccess;
-	});
+	if (!up.start(chunks, [=](size_t k) {
+		    const uint64_t s0 = k * per, s1 = s0 + per < nsb ? s0 + per : nsb;
+		    uint8_t* d = chunk_frame(k);
+		    return hipMemcpyAsync(d, hdrp + 12 * k, H, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+			   hipMemcpyAsync(d + H, in + idx[s0], idx[s1] - idx[s0], hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+			   hipMemcpyAsync(d_rel + s0 + k, relp + s0 + k, (s1 - s0 + 1) * 8, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+			   hipStreamSynchronize(up_stream) == hipSuccess;
+	    }))
+		return STENOS_ERROR_ALLOC;
 	for (size_t k = 0; k < chunks; ++k) {
 		if (!up.wait_for(k))
 			return STENOS_ERROR_UNDEFINED;

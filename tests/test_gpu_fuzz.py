@@ -1,0 +1,52 @@
+"""Randomised differential test of the shipped library against the oracle: bytesoftype, data kind, length and destination
+capacity drawn at random (seeded).  Runs for STENOS_FUZZ_SECONDS (default 20) seconds."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from _libs import has_error, np_ptr, oracle_compress
+from stenos_amd.api import load_library
+from stenos_amd.datagen import generate
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst", "mixed", "lzmix"]
+
+
+def test_random_cases_against_oracle(oracle):
+    lib = load_library()
+    ctx = lib.stenos_make_context()
+    rng = np.random.default_rng(int(os.environ.get("STENOS_FUZZ_SEED", "20261003")))
+    budget = float(os.environ.get("STENOS_FUZZ_SECONDS", "20"))
+    t0, cases = time.time(), 0
+    while time.time() - t0 < budget:
+        r = rng.random()
+        T = int(rng.integers(2, 17)) if r < 0.55 else int(rng.integers(17, 65)) if r < 0.8 else int(rng.integers(65, 600)) if r < 0.97 else int(rng.integers(600, 9000))
+        kind = KINDS[int(rng.integers(len(KINDS)))]
+        bs = 256 * T
+        per = (131072 // bs * 256) if bs <= 131072 else 256
+        shape = rng.random()
+        n = int(rng.integers(1, 300)) if shape < 0.2 else int(rng.integers(1, 3 * per)) if shape < 0.9 else int(rng.integers(3 * per, 8 * per))
+        n = min(n, (48 << 20) // T)
+        seed = int(rng.integers(1 << 30))
+        data = generate(kind, T, n, seed)
+        bound = lib.stenos_bound(data.nbytes)
+        cap = bound if rng.random() < 0.6 else int(rng.integers(0, bound + 1))
+        r1, ref = oracle_compress(oracle, data, T, 1, cap)
+        out = np.full(cap + 64, 0xA5, dtype=np.uint8)
+        lib.stenos_set_level(ctx, 1)
+        r2 = lib.stenos_compress_generic(ctx, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
+        what = (T, kind, n, seed, cap)
+        assert (out[cap:] == 0xA5).all(), what
+        assert has_error(r1) == has_error(r2), what
+        if not has_error(r1):
+            assert r1 == r2 and np.array_equal(ref, out[:r2]), what
+            back = np.full(data.nbytes + 64, 0x5A, dtype=np.uint8)
+            r3 = lib.stenos_decompress_generic(ctx, np_ptr(out), T, r2, np_ptr(back), data.nbytes)
+            assert r3 == data.nbytes and np.array_equal(back[: data.nbytes], data) and (back[data.nbytes:] == 0x5A).all(), what
+        cases += 1
+    lib.stenos_destroy_context(ctx)
+    assert cases > 0
+    print(f"{cases} random cases")
