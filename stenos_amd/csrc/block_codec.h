@@ -1081,21 +1081,21 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	Lds win = lds + L.win;
 	const uint32_t nh = (lines + 1) >> 1;
 	WV_MARK("dec_plane_rows");
-	// ---- row view: every group of 16 lanes computes the same 16 rows ----
-	const U32 r = lane & 15u;
-	const Pred act = r < U32(lines);
+	// ---- row view: lane l looks at row l >> 2, the row of its four elements (the four lanes of a quad compute the same) ----
+	const U32 row = lane >> 2, q = lane & 3u;
+	const Pred act = row < U32(lines);
 	// No size checks here: whatever the stream says, a plane reads at most 8 + 18 + 16*18 + 8 bytes from its start (the
 	// window's buffer is followed by that much readable LDS, superblock_codec.h make_dec_layout) and the caller compares
 	// the bytes consumed by the whole block with the bytes there are (block_compress.h:1702, 1724-1745, 2056, 2071-2084).
 	(void)avail;
 	uint32_t minslen;
 	U32 hdr, minv;
-	hdr = (lds_ld8(win, U32(cur) + (r >> 1)) >> ((r & 1u) << 2)) & 0xFu;
+	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
 	if (type == PLANE_NORMAL) {
 		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));
 		U32 e = sel(emit, U32(1u), U32(0u));
-		U32 ex = row_excl_scan(e);
-		minslen = readlane(ex + e, 15); // the last row's inclusive value is the total
+		U32 ex = quads_excl_scan(e);
+		minslen = readlane(ex + e, 63); // the last row's inclusive value is the total
 		minv = lds_ld8(win, U32(cur + nh) + sel(emit, ex, U32(0u)));
 	}
 	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins
@@ -1103,41 +1103,35 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		uint32_t nlit = 16 - (uint32_t)__builtin_popcount(mask);
 		minslen = 2 + nlit;
 		// min[r] = literal of the last row r' <= r whose mask bit is 0, or 0 when there is none
-		U32 upto = (~U32(mask)) & ((U32(2u) << r) - 1u) & 0xFFFFu;
+		U32 upto = (~U32(mask)) & ((U32(2u) << row) - 1u) & 0xFFFFu;
 		U32 idx = popc(upto);
 		minv = sel(idx == U32(0u), U32(0u), lds_ld8(win, U32(cur + 10) + sel(idx == U32(0u), U32(0u), idx - 1u)));
 	}
 	// row payload sizes; rle rows need their mask, found by walking them in order
 	Pred isrle = act & ((hdr == U32(6u)) | (hdr == U32(7u)));
 	U32 known = sel(act & !isrle, sel(hdr == U32(15u), U32(16u), (hdr & 7u) * 2u), U32(0u));
-	U32 pre = row_excl_scan(known);
-	const uint32_t totals = readlane(pre + known, 15);
+	U32 pre = quads_excl_scan(known);
+	const uint32_t totals = readlane(pre + known, 63);
 	U32 rmask(0u), extra(0u);
 	const uint32_t base = cur + nh + minslen;
-	uint32_t todo = (uint32_t)(ballot(isrle) & 0xFFFFu);
-	const bool has_rle = todo != 0, has_raw = (ballot(act & (hdr == U32(15u))) & 0xFFFFu) != 0; // row kinds present: the element view skips what no row needs
+	uint64_t todo = ballot(isrle) & 0x1111111111111111ull; // one bit per row: that of its first lane
+	const bool has_rle = todo != 0, has_raw = ballot(act & (hdr == U32(15u))) != 0; // row kinds present: the element view skips what no row needs
 	uint32_t rle_total = 0;
 	while (todo) {
-		uint32_t rr = (uint32_t)__builtin_ctz(todo);
+		uint32_t rl = (uint32_t)__builtin_ctzll(todo); // first lane of the row
 		todo &= todo - 1;
-		uint32_t addr = base + readlane(pre + extra, rr);
+		uint32_t addr = base + readlane(pre + extra, rl);
 		uint32_t m = win_u16(win, addr);
 		uint32_t sz = 2 + 16 - (uint32_t)__builtin_popcount(m);
-		rmask = sel(r == U32(rr), U32(m), rmask);
-		extra = extra + sel(r > U32(rr), U32(sz), U32(0u));
+		rmask = sel(row == U32(rl >> 2), U32(m), rmask);
+		extra = extra + sel(row > U32(rl >> 2), U32(sz), U32(0u));
 		rle_total += sz;
 	}
 	uint32_t psize = nh + minslen + (totals & 0xFFFFu) + rle_total;
-	U32 poff = U32(base) + pre + extra;
 
 	WV_MARK("dec_plane_elems");
-	// ---- element view: lane l owns elements 4l..4l+3, its row is l>>2 ----
-	const U32 row = lane >> 2, q = lane & 3u;
-	// (window offsets fit 16 bits up to bytesoftype 128; beyond, the offset travels on its own)
-	const bool near = T <= 128;
-	U32 info = shfl(hdr | (minv << 8) | (near ? poff << 16 : U32(0u)), row);
-	U32 emask = has_rle ? shfl(rmask, row) : U32(0u);
-	U32 eh = info & 0xFFu, emin = (info >> 8) & 0xFFu, eoff = near ? info >> 16 : shfl(poff, row);
+	// ---- element view: lane l owns elements 4l..4l+3 of its row ----
+	const U32 eh = hdr, emin = minv, eoff = U32(base) + pre + extra, emask = rmask;
 	Pred eact = row < U32(lines);
 	Pred e15 = eh == U32(15u), e7 = eh == U32(7u), e6 = eh == U32(6u);
 	Pred erle = e7 | e6;
@@ -1145,9 +1139,9 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 bits = eh & 7u;
 	U32 bitoff = (q & 1u) * bits * 4u;
 	U32 px = lds_ld32_unaligned(win, sel(eact, eoff + (q >> 1) * bits + (bitoff >> 3), U32(0u))) >> (bitoff & 7u);
-	U32 vm = (U32(1u) << bits) - 1u;
-	U32 y = (px & vm) | (((px >> bits) & vm) << 8) | (((px >> (bits * 2u)) & vm) << 16) | (((px >> (bits * 3u)) & vm) << 24);
-	U32 packed = bytes_add(y, bytes_splat(emin));
+	// value k + the row's minimum, mod 256: four sums, their low bytes gathered
+	U32 v0 = bfe(px, U32(0u), bits) + emin, v1 = bfe(px, bits, bits) + emin, v2 = bfe(px, bits * 2u, bits) + emin, v3 = bfe(px, bits * 3u, bits) + emin;
+	U32 packed = perm_bytes(perm_bytes(v3, v2, 0x0c0c0400u), perm_bytes(v1, v0, 0x0c0c0400u), 0x05040100u);
 	// raw row bytes
 	U32 rawv(0u);
 	if (has_raw)
@@ -1180,16 +1174,17 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		// nearest absolute lane before it plus the deltas in between: two wave scans (sum, position of the last absolute
 		// lane) and one gather instead of six rounds of function composition.
 		const Pred dl = A != U32(0u);
-		U32 p = bytes_add(Bw, Bw << 8);
-		p = bytes_add(p, p << 16); // byte k: d0 + .. + dk
-		const U32 total = sel(dl, p >> 24, U32(0u));
+		const U32 sum4 = dot4_u8(Bw, 0x01010101u, U32(0u)); // d0 + d1 + d2 + d3, not reduced: 64 of them still fit 16 bits
+		const U32 total = sel(dl, sum4, U32(0u));
 		const U32 P = wave_incl_scan(total);
 		const U32 start = wave_incl_scan_max(sel(dl, U32(0u), lane + 1u)); // 1 + the last absolute lane up to here, 0: none
 		const U32 sprev = shfl_up(start, 1, 0), Pprev = shfl_up(P, 1, 0);
 		const U32 g = shfl((P & 0xFFFFu) | ((Bw >> 24) << 16), sel(sprev == U32(0u), U32(0u), sprev - 1u));
 		const U32 gP = sel(sprev == U32(0u), U32(0u), g & 0xFFFFu), gB = sel(sprev == U32(0u), U32(0u), g >> 16);
 		const U32 carry = (gB + Pprev - gP) & 0xFFu;
-		outw = sel(dl, bytes_add(p, bytes_splat(carry)), Bw);
+		// byte k: carry + d0 + .. + dk (mod 256)
+		const U32 p0 = dot4_u8(Bw, 0x00000001u, carry), p1 = dot4_u8(Bw, 0x00000101u, carry), p2 = dot4_u8(Bw, 0x00010101u, carry), p3 = sum4 + carry;
+		outw = sel(dl, perm_bytes(perm_bytes(p3, p2, 0x0c0c0400u), perm_bytes(p1, p0, 0x0c0c0400u), 0x05040100u), Bw);
 	}
 	else {
 		U32 cin = chain_carry(A, Bw, 63);

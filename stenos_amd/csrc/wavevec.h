@@ -165,6 +165,25 @@ WV_FN U32 mulhi(const U32& a, const U32& b)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(((uint64_t)a.l[i] * b.l[i]) >> 32);
 	return r;
 }
+// v_bfe_u32: `width` (< 32) bits of x from bit `off` (< 32) on
+WV_FN U32 bfe(const U32& x, const U32& off, const U32& width)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (x.l[i] >> (off.l[i] & 31u)) & ((1u << (width.l[i] & 31u)) - 1u);
+	return r;
+}
+// v_dot4_u32_u8: c + a.b0*b.b0 + a.b1*b.b1 + a.b2*b.b2 + a.b3*b.b3
+WV_FN U32 dot4_u8(const U32& a, uint32_t b, const U32& c)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint32_t s = c.l[i];
+		for (int k = 0; k < 4; ++k)
+			s += ((a.l[i] >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);
+		r.l[i] = s;
+	}
+	return r;
+}
 WV_FN U32 mul24(const U32& a, const U32& b)
 {
 	U32 r;
@@ -491,6 +510,8 @@ WV_FN U32 pk_max_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_el
 WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
 WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 mul24(U32 a, U32 b) { return __umul24(a, b); } // low 24 bits of both operands, full rate
+WV_FN U32 dot4_u8(U32 a, uint32_t b, U32 c) { return __builtin_amdgcn_udot4(a, b, c, false); } // c + sum of the four byte products
+WV_FN U32 bfe(U32 x, U32 off, U32 width) { return __builtin_amdgcn_ubfe(x, off, width); }
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN U32 perm_bytes_v(U32 hi, U32 lo, U32 selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -927,6 +948,18 @@ WV_FN U32 wave_incl_scan(U32 s)
 	return s;
 }
 #endif
+
+// Sixteen values, one per quad of lanes (the four lanes of a quad hold the same value): exclusive prefix sum over the
+// quads, again the same in the four lanes of a quad.  The wave scan without its two in-quad steps.
+WV_FN U32 quads_excl_scan(const U32& x)
+{
+	U32 s = x;
+	s = s + scan_source(s, 2, 0);
+	s = s + scan_source(s, 3, 0);
+	s = s + scan_source(s, 4, 0);
+	s = s + scan_source(s, 5, 0);
+	return s - x;
+}
 
 // ---- SWAR on four packed bytes ----
 WV_FN U32 bytes_sub(const U32& a, const U32& b) // per-byte a - b (mod 256)
