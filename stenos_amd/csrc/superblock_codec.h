@@ -198,17 +198,18 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				WV_MARK("plane_offsets");
 				const SlotPlace P = slot_rows_place(R, B, T);
 				if (T == 4) {
-					// Those that pass the first two rejection tests (most fail the first, noise the second).  The key counts
-					// cover the first 40 values; only a block they do not turn away is looked at again.
+					// Those that pass the rejection tests.  The key counts cover the first 40 values (most blocks fail there); a block
+					// they do not turn away is looked at again: first the test that turns noise and floats away (values that hardly
+					// repeat), then the key count over all 80 values.
 					// (constant indices: a loop over the blocks would send the batch's scalars through memory)
 					if (B.full[0] * 3 > bs && lz_precheck_passes(T, keys0, B.full[0])) {
 						const RawBlock e = load_raw_block(a, T);
-						if (lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[0]) && !lz_repeats_reject(lds, M, e.e, B.full[0]))
+						if (!lz_repeats_reject(lds, M, e.e, B.full[0]) && lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[0]))
 							lzq |= 1u;
 					}
 					if (nblk > 1 && B.full[1] * 3 > bs && lz_precheck_passes(T, keys1, B.full[1])) {
 						const RawBlock e = load_raw_block(b, T);
-						if (lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[1]) && !lz_repeats_reject(lds, M, e.e, B.full[1]))
+						if (!lz_repeats_reject(lds, M, e.e, B.full[1]) && lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[1]))
 							lzq |= 2u;
 					}
 				}
