@@ -261,61 +261,15 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 		stream_flush(sink.rs, lds, L.out);
 	return sink.rs.pos;
 }
-// HBM -> HBM copy of n bytes by one wave with 16-byte stores.  The source is read in aligned 16-byte groups, each of which
-// holds at least one byte of [src, src + n): such a load may cover up to 15 bytes in front of src or behind src + n, but
-// never leaves the page of a byte that belongs to the buffer.
-// dwords DSEL .. DSEL + 4 of {a, b}, shifted right by sh bits: 16 bytes that start (4 * DSEL + sh / 8) bytes into a
-template <uint32_t DSEL>
-WV_FN U128 funnel128(const U128& a, const U128& b, uint32_t sh)
-{
-	const U32 t0 = DSEL == 0 ? a.x : DSEL == 1 ? a.y : DSEL == 2 ? a.z : a.w;
-	const U32 t1 = DSEL == 0 ? a.y : DSEL == 1 ? a.z : DSEL == 2 ? a.w : b.x;
-	const U32 t2 = DSEL == 0 ? a.z : DSEL == 1 ? a.w : DSEL == 2 ? b.x : b.y;
-	const U32 t3 = DSEL == 0 ? a.w : DSEL == 1 ? b.x : DSEL == 2 ? b.y : b.z;
-	const U32 t4 = DSEL == 0 ? b.x : DSEL == 1 ? b.y : DSEL == 2 ? b.z : b.w;
-	U128 v;
-	if (sh) {
-		v.x = (t0 >> U32(sh)) | (t1 << U32(32u - sh));
-		v.y = (t1 >> U32(sh)) | (t2 << U32(32u - sh));
-		v.z = (t2 >> U32(sh)) | (t3 << U32(32u - sh));
-		v.w = (t3 >> U32(sh)) | (t4 << U32(32u - sh));
-	}
-	else {
-		v.x = t0;
-		v.y = t1;
-		v.z = t2;
-		v.w = t3;
-	}
-	return v;
-}
-// `groups` 16-byte groups to the aligned address d, from the bytes that start smis = 4 * DSEL + sh / 8 bytes behind the
-// aligned address sbase.  COPY_ROUNDS rounds of 64 groups at a time: all their loads are requested before the first
-// store, so the rounds cost one memory round trip.
+// HBM -> HBM copy of n bytes by one wave: the destination is written in aligned 16-byte groups (bytes in front of the
+// first and behind the last), the source read with 16-byte loads from whatever byte address that makes -- gfx9 and later
+// serve unaligned global accesses in hardware, so no lane reads a byte outside [src, src + n) and nothing has to be
+// shifted together from two aligned groups.  COPY_ROUNDS rounds of 64 groups at a time: all their loads are requested
+// before the first store, so the rounds cost one memory round trip.
 #ifndef STENOS_COPY_ROUNDS
-#define STENOS_COPY_ROUNDS 2
+#define STENOS_COPY_ROUNDS 4
 #endif
 constexpr uint32_t COPY_ROUNDS = STENOS_COPY_ROUNDS;
-template <uint32_t DSEL>
-WV_FN void copy_groups(uint8_t* d, const uint8_t* sbase, uint32_t groups, uint32_t sh, bool aligned)
-{
-	const U32 lane = lane_id();
-	for (uint32_t o = 0; o < groups; o += 64 * COPY_ROUNDS) {
-		U128 a[COPY_ROUNDS], b[COPY_ROUNDS];
-		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
-			const U32 k = U32(o + 64 * q) + lane;
-			a[q] = gld128(sbase, k * 16u, k < U32(groups));
-		}
-		if (!aligned)
-			for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
-				const U32 k = U32(o + 64 * q) + lane;
-				b[q] = gld128(sbase, k * 16u + 16u, k < U32(groups));
-			}
-		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
-			const U32 k = U32(o + 64 * q) + lane;
-			gst128(d, k * 16u, aligned ? a[q] : funnel128<DSEL>(a[q], b[q], sh), k < U32(groups));
-		}
-	}
-}
 WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 {
 	const U32 lane = lane_id();
@@ -326,14 +280,18 @@ WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 		gst8(dst, lane, gld8(src, lane, p), p);
 	}
 	const uint32_t groups = (n - h) >> 4;
-	const uint32_t smis = (uint32_t)((uintptr_t)(src + h) & 15u);
-	const uint8_t* sbase = src + h - smis; // 16-byte aligned
-	const uint32_t sh = (smis & 3u) * 8u;
-	switch (smis >> 2) { // which dwords of the two aligned groups make up a destination group: decided once, not per lane
-		case 0: copy_groups<0>(dst + h, sbase, groups, sh, smis == 0); break;
-		case 1: copy_groups<1>(dst + h, sbase, groups, sh, false); break;
-		case 2: copy_groups<2>(dst + h, sbase, groups, sh, false); break;
-		default: copy_groups<3>(dst + h, sbase, groups, sh, false); break;
+	uint8_t* d = dst + h;
+	const uint8_t* s = src + h;
+	for (uint32_t o = 0; o < groups; o += 64 * COPY_ROUNDS) {
+		U128 a[COPY_ROUNDS];
+		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+			const U32 k = U32(o + 64 * q) + lane;
+			a[q] = gld128_unaligned(s, k * 16u, k < U32(groups));
+		}
+		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+			const U32 k = U32(o + 64 * q) + lane;
+			gst128(d, k * 16u, a[q], k < U32(groups));
+		}
 	}
 	const uint32_t done = h + groups * 16;
 	{

@@ -404,6 +404,7 @@ WV_FN U128 gld128(const uint8_t* g, const U32& off, const Pred& p) // 16-byte al
 		}
 	return r;
 }
+WV_FN U128 gld128_unaligned(const uint8_t* g, const U32& off, const Pred& p) { return gld128(g, off, p); } // any byte address
 WV_FN void gst8(uint8_t* g, const U32& off, const U32& v, const Pred& p)
 {
 	for (int i = 0; i < WAVE; ++i)
@@ -677,6 +678,17 @@ WV_FN U128 gld128(const uint8_t* g, U32 off, Pred p)
 	U128 r = { 0u, 0u, 0u, 0u };
 	if (p) {
 		uint4 v = *(const uint4*)(g + off);
+		r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+	}
+	return r;
+}
+// 16 bytes from any byte address (gfx9 and later serve unaligned global accesses in hardware)
+WV_FN U128 gld128_unaligned(const uint8_t* g, U32 off, Pred p)
+{
+	typedef uint4 __attribute__((aligned(1))) uint4_u;
+	U128 r = { 0u, 0u, 0u, 0u };
+	if (p) {
+		uint4 v = *(const uint4_u*)(g + off);
 		r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
 	}
 	return r;
