@@ -411,4 +411,149 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	wave_sync();
 }
 
+// A wide batch: three or four consecutive blocks with at most one non-constant plane each (small integers in wide
+// elements, one byte that varies): the slots two such blocks leave free take the blocks behind them.  No mini-LZ in such
+// a batch (a block with one plane is below its size threshold, block_compress.h:1210), and a plane is the only one of its
+// block.  (Letting blocks with two planes into such batches as well was measured: the general placement costs the
+// common two-block pass 3 % in registers and gains nothing.)
+struct SlotBatch4 {
+	uint32_t act[4], first[4]; // per block; constant indices only (a loop over the blocks would send them through memory)
+	uint32_t nblk, nslots;
+	uint32_t full[4];          // sum of the plane sizes of each block
+};
+WV_HD uint32_t pick4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
+// base[q] receives the image offset of block q (the first one at img_base), *bbase that of its slot's block per lane
+WV_FN SlotPlace slot_rows_place4(const SlotRows& R, SlotBatch4& B, uint32_t T, const uint32_t hs, uint32_t img_base, uint32_t* base, U32* bbase)
+{
+	SlotPlace P;
+	const U32 lane = lane_id();
+	const U32 s = lane >> 4;
+	// the slots are the set bits of act[0] | act[1] << 4 | act[2] << 8 | act[3] << 12 in order
+	uint32_t m = B.act[0] | (B.act[1] << 4) | (B.act[2] << 8) | (B.act[3] << 12) | 0xF0000u, pos[4];
+	for (int i = 0; i < 4; ++i) {
+		pos[i] = (uint32_t)__builtin_ctz(m);
+		m &= m - 1u;
+	}
+	const U32 posv = row_select4(pos[0], pos[1], pos[2], pos[3]);
+	P.k = posv & 3u;
+	P.blk = posv >> 2;
+	P.valid = s < U32(B.nslots);
+	// every block has at most one slot: its plane's size is the block's plane sum
+	const uint32_t z0 = readlane(R.size, 0), z1 = readlane(R.size, 16), z2 = readlane(R.size, 32), z3 = readlane(R.size, 48);
+	const uint32_t n0 = B.act[0] ? 1u : 0u, n1 = B.act[1] ? 1u : 0u, n2 = B.act[2] ? 1u : 0u, n3 = B.act[3] ? 1u : 0u;
+	const uint32_t s1 = n0, s2 = n0 + n1, s3 = n0 + n1 + n2; // the slot blocks 1, 2, 3 would take
+	B.full[0] = (n0 ? z0 : 0u) + (T - n0);
+	B.full[1] = (n1 ? pick4(s1, z0, z1, z2, z3) : 0u) + (T - n1);
+	B.full[2] = B.nblk > 2 ? (n2 ? pick4(s2, z0, z1, z2, z3) : 0u) + (T - n2) : 0u;
+	B.full[3] = B.nblk > 3 ? (n3 ? pick4(s3, z0, z1, z2, z3) : 0u) + (T - n3) : 0u;
+	base[0] = img_base;
+	base[1] = base[0] + hs + B.full[0];
+	base[2] = base[1] + hs + B.full[1];
+	base[3] = base[2] + hs + B.full[2];
+	const uint32_t b0 = pos[0] >> 2, b1 = pos[1] >> 2, b2 = pos[2] >> 2, b3 = pos[3] >> 2; // block of each slot
+#define STENOS_PER_SLOT(a, b, c, d) row_select4(pick4(b0, a, b, c, d), pick4(b1, a, b, c, d), pick4(b2, a, b, c, d), pick4(b3, a, b, c, d))
+	P.act = STENOS_PER_SLOT(B.act[0], B.act[1], B.act[2], B.act[3]);
+	P.first = STENOS_PER_SLOT(B.first[0], B.first[1], B.first[2], B.first[3]);
+	*bbase = STENOS_PER_SLOT(base[0], base[1], base[2], base[3]);
+#undef STENOS_PER_SLOT
+	// the planes in front of mine in my block are SAME ones: a byte each
+	P.pbase = U32(hs) + P.k;
+	return P;
+}
+
+// The same for a wide batch: block q of the batch starts at byte base[q] of the image, bbase is that of the lane's slot.
+WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows& R, const SlotPlace& P, const SlotBatch4& B, const U32& bbase, const uint32_t* base)
+{
+	const U32 lane = lane_id();
+	const U32 r = lane & 15u;
+	const U32 H(0x80808080u);
+	Lds out = lds + L.out;
+	const uint32_t hs = header_bytes(T);
+	const U32 own = lane * 4u; // where lanes with nothing to write OR their zeros
+	WV_MARK("emit_nibbles");
+	const U32 pbase = bbase + P.pbase;
+	{
+		// One small write per lane of a slot: lane 0 the plane's type nibble (:1246-1257); lanes 1..3 the bytes of the SAME
+		// planes that follow the plane directly; lanes 4..7 of a block's first slot the SAME planes in front of it (:747-750).
+		const U32 after = r - 1u, before = r - 4u;
+		const Pred follows = (r >= U32(1u)) & (r < U32(4u)) & (P.k + r < U32(T)) & (((P.act >> (P.k + 1u)) & ((U32(1u) << r) - 1u)) == U32(0u));
+		const Pred leads = (r >= U32(4u)) & (r < U32(8u)) & (before < P.k) & ((P.act & ((U32(1u) << P.k) - 1u)) == U32(0u));
+		const U32 plane = sel(follows, P.k + r, before);
+		const U32 byte = (P.first >> (plane << 3)) & 0xFFu;
+		const U32 where = sel(follows, pbase + R.size + after, bbase + U32(hs) + before);
+		const Pred nib = r == U32(0u);
+		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type, byte), P.valid & (nib | follows | leads), own);
+	}
+	// a block without a slot: its SAME bytes (the type nibbles are all 0); constant indices keep the batch in scalar registers
+#define STENOS_SAME_ONLY(q)                                                                                             \
+	if (q < B.nblk && B.act[q] == 0) {                                                                               \
+		const U32 byte = (U32(B.first[q]) >> (lane << 3)) & 0xFFu;                                                     \
+		put_small(out, (U32(base[q] + hs) + lane) * 8u, byte, lane < U32(T), own);                                     \
+	}
+	STENOS_SAME_ONLY(0)
+	STENOS_SAME_ONLY(1)
+	STENOS_SAME_ONLY(2)
+	STENOS_SAME_ONLY(3)
+#undef STENOS_SAME_ONLY
+	if (B.nslots == 0) {
+		wave_sync();
+		return;
+	}
+	WV_MARK("emit_rowlanes");
+	const U32 hdr = R.hdr;
+	const Pred israw = P.valid & (R.type == U32(PLANE_RAW));
+	const Pred normal = P.valid & !israw;
+	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
+	put_small(out, (pbase + R.minpos) * 8u, R.minb ^ 0x80u, normal & R.emitmin, own);
+	{
+		// mins rle mask (:765): bit r = min equals previous min
+		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
+		if (any(isnrle)) {
+			const uint64_t eqb = ballot(R.eq);
+			const U32 m16 = row_select4((uint32_t)eqb & 0xFFFFu, (uint32_t)(eqb >> 16) & 0xFFFFu, (uint32_t)(eqb >> 32) & 0xFFFFu, (uint32_t)(eqb >> 48));
+			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
+		}
+	}
+	WV_MARK("emit_plane");
+	const Pred is15 = hdr == U32(15u), isr = (hdr & 14u) == U32(6u);
+	const U32 bits = hdr & 7u;
+	const Pred rawrow = israw | (normal & is15);
+	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
+	const Pred rle = normal & isr;
+	const U32 rbase = pbase + sel(israw, r * 16u, R.poff);
+	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each; value - minimum on biased bytes
+	const Pred usedelta = hdr >= U32(8u);
+	const U32 mins = splat_byte0(R.minb);
+	U32 pk[4];
+	for (int k = 0; k < 4; ++k)
+		pk[k] = pack4v(sel(usedelta, R.sd[k], R.sb[k]) - mins, bits);
+	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
+	const Pred anyw = rawrow | packed;
+	const U32 s0lo = sel(rawrow, R.sb[0] ^ H, sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
+	const U32 s0hi = sel(rawrow, R.sb[1] ^ H, sel(packed, pk[1] >> ish4, U32(0u)));
+	const U32 s1lo = sel(rawrow, R.sb[2] ^ H, sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
+	const U32 s1hi = sel(rawrow, R.sb[3] ^ H, sel(packed, pk[3] >> ish4, U32(0u)));
+	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
+	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
+	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
+	if (any(rle)) {
+		const Pred is7 = hdr == U32(7u);
+		U32 f16(0u), lp = rbase + 2u;
+		for (int k = 0; k < 4; ++k) {
+			// byte == previous byte (:268-275) / delta == previous delta (:248-255)
+			const U32 bp = k ? prev_bytes(R.sb[k], R.sb[k - 1]) : prev_bytes(R.sb[0], row_shr(R.sb[3], 1, 0x80808080u));
+			const U32 dp = k ? prev_bytes(R.sd[k], R.sd[k - 1]) : ((R.sd[0] << 8) | 0x80u);
+			const U32 z = bytes_zero_mask(sel(is7, R.sb[k] ^ bp, R.sd[k] ^ dp));
+			const U32 f = zero_mask_to_bits(z);
+			f16 = f16 | (f << U32(4u * (uint32_t)k));
+			const U32 nlit = U32(4u) - popc(f);
+			put_bits(out, lp * 8u, compact_unflagged(sel(is7, R.sb[k], R.sd[k]) ^ H, f), rle & (nlit != U32(0u)), own);
+			lp = lp + nlit;
+		}
+		put_bits(out, rbase * 8u, f16, rle, own);
+	}
+	WV_MARK("emit_end");
+	wave_sync();
+}
+
 } // namespace codec

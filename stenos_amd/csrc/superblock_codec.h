@@ -185,7 +185,59 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				if (nblk > 1)
 					write_slots_fast(lds, M, eb, T, B.act[1], B.nact0);
 				B.nblk = nblk;
+				// Two blocks with at most one non-constant plane each leave slots free: the blocks behind them move in while
+				// they have at most one such plane themselves (a wide batch, slot_codec.h).
+				SlotBatch4 W;
+				W.nblk = 0;
+				if (nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
+					const bool has_d = i + 3 < nblocks;
+					const RawBlock ec = load_raw_block(b + bs, T);
+					RawBlock ed;
+					if (has_d)
+						ed = load_raw_block(b + 2 * bs, T);
+					const SameScan sc = scan_same_fast(ec, T);
+					if (sc.nact <= 1) {
+						W.act[0] = B.act[0], W.act[1] = B.act[1], W.act[2] = sc.act, W.act[3] = 0;
+						W.first[0] = B.first[0], W.first[1] = B.first[1], W.first[2] = sc.first, W.first[3] = 0;
+						write_slots_fast(lds, M, ec, T, sc.act, B.nslots);
+						W.nslots = B.nslots + sc.nact;
+						W.nblk = 3;
+						if (has_d) {
+							const SameScan sd = scan_same_fast(ed, T);
+							if (sd.nact <= 1) {
+								W.act[3] = sd.act;
+								W.first[3] = sd.first;
+								write_slots_fast(lds, M, ed, T, sd.act, W.nslots);
+								W.nslots += sd.nact;
+								W.nblk = 4;
+							}
+						}
+						nblk = W.nblk;
+					}
+				}
 				wave_sync();
+				if (W.nblk) {
+					SlotRows R;
+					if (W.nslots)
+						slot_rows_analyse(lds, M, R);
+					else {
+						for (int k = 0; k < 4; ++k)
+							R.sb[k] = R.sd[k] = U32(0u);
+						R.hdr = R.minb = R.poff = R.minpos = R.type = R.size = U32(0u);
+						R.emitmin = R.eq = pred_all(false);
+					}
+					uint32_t base[4];
+					U32 bbase;
+					const SlotPlace P = slot_rows_place4(R, W, T, hs, sink.base(), base, &bbase);
+					const uint32_t total = base[3] + (W.nblk > 3 ? hs + W.full[3] : 0u) - base[0];
+					if (sink.writes) {
+						image_reset(lds, M, base[0], total);
+						slot_rows_emit4(lds, M, T, R, P, W, bbase, base);
+					}
+					sink.append(lds, M, total);
+					i += nblk;
+					continue;
+				}
 				SlotRows R;
 				if (B.nslots)
 					slot_rows_analyse(lds, M, R);

@@ -47,7 +47,7 @@ def _le_elements(x: np.ndarray, T: int) -> np.ndarray:
 def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     """Return n elements of T bytes as a flat uint8 array.
 
-    kinds: sorted_i32 (README example, T=4), rand (full entropy), rand12 (u & 0xFFF, T=4),
+    kinds: sorted_i32 (README example, T=4), rand (full entropy), rand12 (u & 0xFFF, T=4), rand8 (u & 0xFF),
     same, sorted (lexicographically sorted random elements, signed bytes as std::array<char,N>),
     walk (x += u%17 - 8), dict16 (16-entry dictionary), runs (runs of 7), burst, ramp,
     sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal),
@@ -66,6 +66,8 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     if kind == "rand12":
         assert T == 4
         return _as_bytes((u & np.uint64(0xFFF)).astype("<u4"))
+    if kind == "rand8":  # small integers in wide elements: one non-constant plane
+        return _le_elements((u & np.uint64(0xFF)).astype(np.int64), T)
     if kind == "same":
         return np.full(n * T, int(u[0] & np.uint64(0xFF)), dtype=np.uint8)
     if kind == "sorted":
@@ -153,7 +155,7 @@ def splitmix64_torch(seed: int, n: int, device, start: int = 0):
 
 def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25, start: int = 0):
     """Flat uint8 CUDA tensor holding elements [start, start + n) of the sequence `kind` (T bytes each);
-    kinds: sorted_i32, rand, rand12, walk (start must be 0), sine."""
+    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine."""
     import torch
 
     out = torch.empty(n * T, dtype=torch.uint8, device=device)
@@ -170,6 +172,8 @@ def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chu
             v = splitmix64_torch(seed, nb, device, start=s * T // 8).view(torch.uint8)[: m * T]
         elif kind == "rand12":
             v = (splitmix64_torch(seed, m, device, start=s) & 0xFFF).to(torch.int32)
+        elif kind == "rand8":
+            v = (splitmix64_torch(seed, m, device, start=s) & 0xFF).to({2: torch.int16, 4: torch.int32, 8: torch.int64}[T])
         elif kind == "walk":
             u = splitmix64_torch(seed, m, device, start=s)
             # u mod 17 for the unsigned 64-bit value: (hi * 2^32 + lo) mod 17 with 2^32 mod 17 = 1

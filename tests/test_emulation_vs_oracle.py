@@ -309,3 +309,41 @@ def test_decoder_image_path_for_small_types(oracle, emul, T):
             r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), 3)
             assert r3 == nb and np.array_equal(dec[:nb], data) and not dec[nb:].any(), (kind, regs)
     emul.emul_set_dec_regs(1)
+
+
+@pytest.mark.parametrize("T,dtype", [(4, "<u4"), (2, "<u2")])
+def test_fused_path_wide_batches(oracle, emul, T, dtype):
+    """Blocks with at most one non-constant plane share a pass three or four at a time (SlotBatch4, slot_codec.h): random
+    sequences of such blocks (one varying byte anywhere in the element, all constant, runs) mixed with blocks of two
+    planes that end a batch, through the fused path."""
+    from _libs import oracle_compress
+
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    emul.emul_last_fused.restype = c_size_t
+    rng = np.random.default_rng(5 + T)
+    for trial in range(6):
+        parts = []
+        for b in range(int(rng.integers(300, 700))):
+            mode = int(rng.integers(0, 8))
+            if mode == 0:
+                v = np.full(256, int(rng.integers(0, 1 << (8 * T))), dtype=np.uint64)
+            elif mode <= 3:
+                v = rng.integers(0, 256, 256, dtype=np.uint64) + (int(rng.integers(0, 1 << (8 * (T - 1)))) << 8)
+            elif mode == 4:
+                v = (rng.integers(0, 256, 256, dtype=np.uint64) << 8) + int(rng.integers(0, 256))
+            elif mode == 5:
+                v = rng.integers(0, 256, 256, dtype=np.uint64) << (8 * (T - 1))
+            elif mode == 6:
+                v = rng.integers(0, 65536, 256, dtype=np.uint64)
+            else:
+                v = np.repeat(rng.integers(0, 256, 16, dtype=np.uint64), 16)
+            parts.append(v)
+        if trial % 2:
+            parts.append(rng.integers(0, 256, int(rng.integers(1, 256)), dtype=np.uint64))
+        data = np.concatenate(parts).astype(dtype).view(np.uint8)
+        r1, ref = oracle_compress(oracle, data, T, 1)
+        out = np.zeros(oracle.so_bound(data.nbytes) + 4096, dtype=np.uint8)  # (ample room: the leading superblocks take the fused path)
+        r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), out.nbytes, 1)
+        assert emul.emul_last_fused() > 0
+        assert r1 == r2 and np.array_equal(ref, out[:r2]), trial

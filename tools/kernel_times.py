@@ -12,7 +12,7 @@ from stenos_amd.api import Stenos  # noqa: E402
 from stenos_amd.datagen import generate_torch  # noqa: E402
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-work = [w.split(":") for w in sys.argv[2:]] or [["rand12", "4"], ["rand", "4"], ["sorted_i32", "4"], ["sine", "4"], ["walk", "2"], ["sine", "8"]]
+work = [w.split(":") for w in sys.argv[2:]] or [["rand12", "4"], ["rand", "4"], ["sorted_i32", "4"], ["rand8", "4"], ["sine", "4"], ["walk", "2"], ["rand8", "2"], ["sine", "8"]]
 tag = os.path.basename(os.environ.get("STENOS_LIB_PATH", "tree"))
 for kind, T in work:
     T = int(T)
