@@ -143,6 +143,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 		// the four slots together, are analysed and written by row lanes in one pass.
 		const uint32_t bs = 256 * T, hs = header_bytes(T);
 		uint32_t i = 0;
+		bool was_wide = false; // the last pass was a wide batch: the next one probably is, and asks for its four blocks at once
 		while (i < nblocks) {
 			const uint8_t* a = src + (uint64_t)i * bs;
 			const uint8_t* b = a + bs;
@@ -154,9 +155,15 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				// its load has at least brought it closer for the next round
 				const bool has_b = i + 1 < nblocks;
 				const RawBlock ea = load_raw_block(a, T);
-				RawBlock eb;
+				RawBlock eb, ec, ed;
 				if (has_b)
 					eb = load_raw_block(b, T);
+				const bool early = was_wide && i + 3 < nblocks;
+				if (early) {
+					ec = load_raw_block(b + bs, T);
+					ed = load_raw_block(b + 2 * bs, T);
+				}
+				was_wide = false;
 				WV_MARK("block_begin");
 				const Layout M = sink.at(L);
 				SlotBatch B;
@@ -191,10 +198,11 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				W.nblk = 0;
 				if (nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
 					const bool has_d = i + 3 < nblocks;
-					const RawBlock ec = load_raw_block(b + bs, T);
-					RawBlock ed;
-					if (has_d)
-						ed = load_raw_block(b + 2 * bs, T);
+					if (!early) {
+						ec = load_raw_block(b + bs, T);
+						if (has_d)
+							ed = load_raw_block(b + 2 * bs, T);
+					}
 					const SameScan sc = scan_same_fast(ec, T);
 					if (sc.nact <= 1) {
 						W.act[0] = B.act[0], W.act[1] = B.act[1], W.act[2] = sc.act, W.act[3] = 0;
@@ -213,6 +221,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 							}
 						}
 						nblk = W.nblk;
+						was_wide = true;
 					}
 				}
 				wave_sync();
