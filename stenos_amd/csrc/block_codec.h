@@ -119,8 +119,8 @@ WV_FN void plane_words_from_int16(PlaneRegs& r, const U32& lo, const U32& hi)
 	r.w[1] = perm_bytes(hi, lo, 0x07050301u);
 	r.w[2] = r.w[3] = U32(0u);
 }
-// Plane words of a block of bytesoftype 2 or 4 straight from HBM (g 16-byte aligned): the second block of a pair is
-// analysed before it is staged in LDS (superblock_codec.h, encode_run).
+// A block of bytesoftype 2 or 4 straight from HBM into registers, from any byte address (gfx9 and later serve unaligned
+// global accesses in hardware: a slice of an array compresses as fast as the array).
 struct RawBlock { // the lane's share of a block of bytesoftype 2 (x, y) or 4 (x, y, z, w): its four elements
 	U128 e;
 };
@@ -128,11 +128,11 @@ WV_FN RawBlock load_raw_block(const uint8_t* g, uint32_t T)
 {
 	RawBlock r;
 	if (T == 2) {
-		gld64(g, lane_id() * 8u, r.e.x, r.e.y);
+		gld64_unaligned(g, lane_id() * 8u, r.e.x, r.e.y);
 		r.e.z = r.e.w = U32(0u);
 	}
 	else
-		r.e = gld128(g, lane_id() * 16u, pred_all(true));
+		r.e = gld128_unaligned(g, lane_id() * 16u, pred_all(true));
 	return r;
 }
 WV_FN PlaneRegs plane_regs_of(const RawBlock& b, uint32_t T)
@@ -1276,7 +1276,7 @@ WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, 
 // A full block of bytesoftype 2, 4 or 8 made of planes (not COPY, not LZ), straight to HBM: the lane's word of every plane
 // stays in a register, three (bytesoftype 2: one) v_perm_b32 per element turn them into the lane's four elements and one
 // or two 16-byte stores write them.  No byte stores into an element-major image (stride 4*T between the lanes: LDS bank
-// conflicts), no image to read back.  g: where the block goes, aligned to 4*T bytes.  head: the type nibbles.
+// conflicts), no image to read back.  g: where the block goes (any byte address).  head: the type nibbles.
 template <uint32_t T>
 WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint32_t avail, uint32_t head, uint8_t* g)
 {
@@ -1309,7 +1309,7 @@ WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint3
 	if (bad || p > end)
 		return DEC_ERROR;
 	if (T == 2)
-		gst64(g, lane * 8u, perm_bytes(w[1], w[0], 0x05010400u), perm_bytes(w[1], w[0], 0x07030602u), pred_all(true));
+		gst64_unaligned(g, lane * 8u, perm_bytes(w[1], w[0], 0x05010400u), perm_bytes(w[1], w[0], 0x07030602u), pred_all(true));
 	else {
 		U32 e[T / 4 ? T / 4 : 1][4]; // e[h][i]: bytes 4h .. 4h+3 of the lane's element i
 		for (uint32_t h = 0; h < T / 4; ++h) {
@@ -1323,13 +1323,13 @@ WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint3
 		U128 v;
 		if (T == 4) {
 			v.x = e[0][0], v.y = e[0][1], v.z = e[0][2], v.w = e[0][3];
-			gst128(g, lane * 16u, v, pred_all(true));
+			gst128_unaligned(g, lane * 16u, v, pred_all(true));
 		}
 		else {
 			v.x = e[0][0], v.y = e[T / 4 - 1][0], v.z = e[0][1], v.w = e[T / 4 - 1][1];
-			gst128(g, lane * 32u, v, pred_all(true));
+			gst128_unaligned(g, lane * 32u, v, pred_all(true));
 			v.x = e[0][2], v.y = e[T / 4 - 1][2], v.z = e[0][3], v.w = e[T / 4 - 1][3];
-			gst128(g, lane * 32u + 16u, v, pred_all(true));
+			gst128_unaligned(g, lane * 32u + 16u, v, pred_all(true));
 		}
 	}
 	return p - cur;
@@ -1337,7 +1337,7 @@ WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint3
 
 // Decode `lines` rows (16 = a full block) of the block whose encoding starts at window offset cur.
 // full: a full block (may be COPY / LZ, planes may be RAW / NORMAL_RLE).
-// g (optional, full blocks of bytesoftype 2, 4, 8 known at compile time): the block's place in HBM, suitably aligned; a
+// g (optional, full blocks of bytesoftype 2, 4, 8 known at compile time): the block's place in HBM; a
 // block made of planes is then written there directly and *direct set, anything else lands in the image as usual.
 // Returns bytes consumed or DEC_ERROR.
 WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail, uint32_t lines, bool full, uint8_t* g = nullptr,

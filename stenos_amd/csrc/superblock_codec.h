@@ -26,40 +26,30 @@ WV_FN void copy_g2l(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
 	lds_st8(lds, U32(ldsoff + full) + lane, gld8(g, U32(full) + lane, t), t);
 }
 // any alignment of g
-WV_FN void copy_g2l_bytes(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
-{
-	const U32 lane = lane_id();
-	for (uint32_t o = 0; o < n; o += 64) {
-		Pred p = (U32(o) + lane) < U32(n);
-		lds_st8(lds, U32(ldsoff + o) + lane, gld8(g, U32(o) + lane, p), p);
-	}
-}
 WV_FN void load_block(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
 {
-	if ((((uintptr_t)g) & 15u) == 0)
-		copy_g2l(lds, ldsoff, g, n);
-	else
-		copy_g2l_bytes(lds, ldsoff, g, n);
+	const U32 lane = lane_id();
+	const uint32_t full = n & ~15u;
+	for (uint32_t o = 0; o < full; o += 1024) {
+		U32 off = U32(o) + lane * 16u;
+		Pred p = off < U32(full);
+		lds_st128(lds, U32(ldsoff) + off, gld128_unaligned(g, off, p), p);
+	}
+	Pred t = lane < U32(n - full);
+	lds_st8(lds, U32(ldsoff + full) + lane, gld8(g, U32(full) + lane, t), t);
 }
 // LDS image -> HBM, never writes past g + n
 WV_FN void store_block(uint8_t* g, Lds lds, uint32_t ldsoff, uint32_t n)
 {
 	const U32 lane = lane_id();
-	if ((((uintptr_t)g) & 15u) == 0) {
-		const uint32_t full = n & ~15u;
-		for (uint32_t o = 0; o < full; o += 1024) {
-			U32 off = U32(o) + lane * 16u;
-			Pred p = off < U32(full);
-			gst128(g, off, lds_ld128(lds, U32(ldsoff) + sel(p, off, U32(0u))), p);
-		}
-		Pred t = lane < U32(n - full);
-		gst8(g, U32(full) + lane, lds_ld8(lds, U32(ldsoff + full) + sel(t, lane, U32(0u))), t);
+	const uint32_t full = n & ~15u;
+	for (uint32_t o = 0; o < full; o += 1024) {
+		U32 off = U32(o) + lane * 16u;
+		Pred p = off < U32(full);
+		gst128_unaligned(g, off, lds_ld128(lds, U32(ldsoff) + sel(p, off, U32(0u))), p);
 	}
-	else
-		for (uint32_t o = 0; o < n; o += 64) {
-			Pred p = (U32(o) + lane) < U32(n);
-			gst8(g, U32(o) + lane, lds_ld8(lds, U32(ldsoff + o) + sel(p, lane, U32(0u))), p);
-		}
+	Pred t = lane < U32(n - full);
+	gst8(g, U32(full) + lane, lds_ld8(lds, U32(ldsoff + full) + sel(t, lane, U32(0u))), t);
 }
 
 // ---- encode side -----------------------------------------------------------------------------------
@@ -150,7 +140,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			WV_MARK("load_block");
 			uint32_t nblk = 1;
 			uint32_t lzq = 0; // blocks of the batch that try the mini-LZ (block_compress.h:1210-1221)
-			if ((((uintptr_t)a) & 15u) == 0) {
+			{
 				// both blocks are requested at once, straight into registers; when the second one is not paired after all,
 				// its load has at least brought it closer for the next round
 				const bool has_b = i + 1 < nblocks;
@@ -288,7 +278,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					continue;
 				}
 			}
-			// a source that is not 16-byte aligned, or a mini-LZ attempt: the general block encoder, one block at a time
+			// a mini-LZ attempt: the general block encoder, one block at a time
 			for (uint32_t q = 0; q < nblk; ++q) {
 				load_block(lds, L.in, q ? b : a, bs);
 				wave_sync();
@@ -433,7 +423,7 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 	const uint8_t* abase = src - mis;
 	uint32_t wstart = 0, wfill = 0, wend = 0; // window holds abase[wstart, wend), wend = wstart + wfill
 	uint32_t consumed = 0;          // payload bytes consumed so far
-	const bool to_hbm = regs && (((uintptr_t)dst) & 15u) == 0;
+	const bool to_hbm = regs;
 
 	auto ensure = [&](uint32_t need) {
 		// make payload bytes [consumed, consumed + need) resident (need already clipped to the payload)

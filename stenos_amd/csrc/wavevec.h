@@ -404,7 +404,9 @@ WV_FN U128 gld128(const uint8_t* g, const U32& off, const Pred& p) // 16-byte al
 		}
 	return r;
 }
-WV_FN U128 gld128_unaligned(const uint8_t* g, const U32& off, const Pred& p) { return gld128(g, off, p); } // any byte address
+// the same accesses at any byte address
+WV_FN U128 gld128_unaligned(const uint8_t* g, const U32& off, const Pred& p) { return gld128(g, off, p); }
+WV_FN void gld64_unaligned(const uint8_t* g, const U32& off, U32& lo, U32& hi) { gld64(g, off, lo, hi); }
 WV_FN void gst8(uint8_t* g, const U32& off, const U32& v, const Pred& p)
 {
 	for (int i = 0; i < WAVE; ++i)
@@ -433,6 +435,8 @@ WV_FN void gst128(uint8_t* g, const U32& off, const U128& v, const Pred& p)
 			memcpy(g + off.l[i] + 12, &v.w.l[i], 4);
 		}
 }
+WV_FN void gst128_unaligned(uint8_t* g, const U32& off, const U128& v, const Pred& p) { gst128(g, off, v, p); }
+WV_FN void gst64_unaligned(uint8_t* g, const U32& off, const U32& lo, const U32& hi, const Pred& p) { gst64(g, off, lo, hi, p); }
 // wave-uniform scalar accesses to global memory
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *p; }
 WV_FN uint32_t gload_uniform8(const uint8_t* p) { return *p; }
@@ -693,6 +697,13 @@ WV_FN U128 gld128_unaligned(const uint8_t* g, U32 off, Pred p)
 	}
 	return r;
 }
+WV_FN void gld64_unaligned(const uint8_t* g, U32 off, U32& lo, U32& hi)
+{
+	typedef uint2 __attribute__((aligned(1))) uint2_u;
+	uint2 v = *(const uint2_u*)(g + off);
+	lo = v.x;
+	hi = v.y;
+}
 WV_FN void gst8(uint8_t* g, U32 off, U32 v, Pred p)
 {
 	if (p) g[off] = (uint8_t)v;
@@ -708,6 +719,16 @@ WV_FN void gst64(uint8_t* g, U32 off, U32 lo, U32 hi, Pred p)
 WV_FN void gst128(uint8_t* g, U32 off, const U128& v, Pred p)
 {
 	if (p) *(uint4*)(g + off) = make_uint4(v.x, v.y, v.z, v.w);
+}
+WV_FN void gst128_unaligned(uint8_t* g, U32 off, const U128& v, Pred p)
+{
+	typedef uint4 __attribute__((aligned(1))) uint4_u;
+	if (p) *(uint4_u*)(g + off) = make_uint4(v.x, v.y, v.z, v.w);
+}
+WV_FN void gst64_unaligned(uint8_t* g, U32 off, U32 lo, U32 hi, Pred p)
+{
+	typedef uint2 __attribute__((aligned(1))) uint2_u;
+	if (p) *(uint2_u*)(g + off) = make_uint2(lo, hi);
 }
 // wave-uniform scalar accesses to global memory (stores by one lane)
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *(const volatile uint32_t*)p; }
