@@ -393,6 +393,19 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
 		const Pred is7 = hdr == U32(7u);
+		// table of the 16 v_perm_b32 selectors that move the bytes whose flag is 0 to the low end (lane f writes entry f;
+		// the slot area is free once the rows are in registers)
+		const uint32_t lut = slot2_area(L);
+		{
+			U32 pat(0x0c0c0c0cu), at(0u);
+			for (uint32_t k = 0; k < 4; ++k) {
+				const Pred keep = ((lane >> k) & 1u) == U32(0u);
+				pat = sel(keep, (pat & ~(U32(0xFFu) << at)) | (U32(k) << at), pat);
+				at = at + sel(keep, U32(8u), U32(0u));
+			}
+			lds_st32(lds, U32(lut) + lane * 4u, pat, lane < U32(16u));
+			wave_sync();
+		}
 		U32 f16(0u), lp = rbase + 2u;
 		for (int k = 0; k < 4; ++k) {
 			// byte == previous byte (:268-275) / delta == previous delta (:248-255)
@@ -402,7 +415,8 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 			const U32 f = zero_mask_to_bits(z);
 			f16 = f16 | (f << U32(4u * (uint32_t)k));
 			const U32 nlit = U32(4u) - popc(f);
-			put_bits(out, lp * 8u, compact_unflagged(sel(is7, R.sb[k], R.sd[k]) ^ H, f), rle & (nlit != U32(0u)), own);
+			const U32 lits = perm_bytes_v(U32(0u), sel(is7, R.sb[k], R.sd[k]) ^ H, lds_ld32(lds, U32(lut) + f * 4u));
+			put_bits(out, lp * 8u, lits, rle & (nlit != U32(0u)), own);
 			lp = lp + nlit;
 		}
 		put_bits(out, rbase * 8u, f16, rle, own);
@@ -538,6 +552,19 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
 		const Pred is7 = hdr == U32(7u);
+		// table of the 16 v_perm_b32 selectors that move the bytes whose flag is 0 to the low end (lane f writes entry f;
+		// the slot area is free once the rows are in registers)
+		const uint32_t lut = slot2_area(L);
+		{
+			U32 pat(0x0c0c0c0cu), at(0u);
+			for (uint32_t k = 0; k < 4; ++k) {
+				const Pred keep = ((lane >> k) & 1u) == U32(0u);
+				pat = sel(keep, (pat & ~(U32(0xFFu) << at)) | (U32(k) << at), pat);
+				at = at + sel(keep, U32(8u), U32(0u));
+			}
+			lds_st32(lds, U32(lut) + lane * 4u, pat, lane < U32(16u));
+			wave_sync();
+		}
 		U32 f16(0u), lp = rbase + 2u;
 		for (int k = 0; k < 4; ++k) {
 			// byte == previous byte (:268-275) / delta == previous delta (:248-255)
@@ -547,7 +574,8 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 			const U32 f = zero_mask_to_bits(z);
 			f16 = f16 | (f << U32(4u * (uint32_t)k));
 			const U32 nlit = U32(4u) - popc(f);
-			put_bits(out, lp * 8u, compact_unflagged(sel(is7, R.sb[k], R.sd[k]) ^ H, f), rle & (nlit != U32(0u)), own);
+			const U32 lits = perm_bytes_v(U32(0u), sel(is7, R.sb[k], R.sd[k]) ^ H, lds_ld32(lds, U32(lut) + f * 4u));
+			put_bits(out, lp * 8u, lits, rle & (nlit != U32(0u)), own);
 			lp = lp + nlit;
 		}
 		put_bits(out, rbase * 8u, f16, rle, own);

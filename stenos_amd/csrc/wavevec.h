@@ -1012,7 +1012,8 @@ WV_FN U32 bytes_zero_mask(const U32& x)
 	return ~(((x & L) + L) | x | L);
 }
 // compress the four 0x80 flags of a zero mask into bits 0..3
-WV_FN U32 zero_mask_to_bits(const U32& z) { return (((z >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu; }
+// (z holds nothing but those flags: the four products land on bits 24..27, every other term below bit 24 or beyond bit 31)
+WV_FN U32 zero_mask_to_bits(const U32& z) { return ((z >> 7) * 0x01020408u) >> 24; }
 WV_FN U32 byte_of(const U32& x, int k) { return (x >> U32(8u * (uint32_t)k)) & 0xFFu; }
 WV_FN U32 bytes_splat(const U32& b) { return (b & 0xFFu) * 0x01010101u; }
 } // namespace wv
