@@ -1001,6 +1001,7 @@ constexpr uint32_t DEC_ERROR = 0xFFFFFFFFu;
 struct DecLayout {
 	uint32_t win;  // window of compressed bytes (+8 slack after the valid bytes)
 	uint32_t img;  // decoded block, element major, 256*T bytes
+	uint32_t lut;  // 16 v_perm_b32 selectors that put the literals of a run-length group back in their places (dec_write_lut)
 	uint32_t total;
 };
 
@@ -1059,18 +1060,19 @@ WV_FN U32 chain_carry(const U32& A, const U32& Bw, uint32_t seg_mask)
 	return ex & 0xFFu; // carry-in for a start value of 0
 }
 
-// expand literals: byte k = flag bit k ? 0 : next literal (literals packed from the low end of lits)
-WV_FN U32 expand_literals(const U32& lits, const U32& f)
+// Entry f of the selector table: byte k of the result = flag bit k of f ? 0 : the next literal.  Lane f writes entry f.
+WV_FN void dec_write_lut(Lds lds, const DecLayout& L)
 {
-	U32 out(0u), n(0u);
-	for (int k = 0; k < 4; ++k) {
-		Pred lit = ((f >> U32((uint32_t)k)) & 1u) == U32(0u);
-		out = out | sel(lit, ((lits >> (n << 3)) & 0xFFu) << U32(8u * (uint32_t)k), U32(0u));
+	const U32 lane = lane_id_plain();
+	U32 pat(0u), n(0u);
+	for (uint32_t k = 0; k < 4; ++k) {
+		const Pred lit = ((lane >> k) & 1u) == U32(0u);
+		pat = pat | (sel(lit, n, U32(0x0cu)) << U32(8u * k));
 		n = n + sel(lit, U32(1u), U32(0u));
 	}
-	return out;
+	lds_st32(lds, U32(L.lut) + lane * 4u, pat, lane < U32(16u));
+	wave_sync();
 }
-
 // Decode one NORMAL / NORMAL_RLE plane whose bytes start at window offset `cur` (at most `avail`
 // valid bytes).  Writes rows [0, lines) of plane j into the image or, with `keep`, hands the lane's plane word back instead.
 // Returns bytes consumed or DEC_ERROR.
@@ -1152,7 +1154,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		f = (emask >> (q << 2)) & 0xFu;
 		U32 litidx = popc((~emask) & ((U32(1u) << (q << 2)) - 1u) & 0xFFFFu);
 		U32 lits = lds_ld32_unaligned(win, sel(eact & erle, eoff + 2u + litidx, U32(0u)));
-		rlev = expand_literals(lits, f);
+		rlev = perm_bytes_v(U32(0u), lits, lds_ld32(lds, U32(L.lut) + f * 4u)); // byte k = flag bit k ? 0 : next literal, through the table
 		// delta-rle rows first rebuild their deltas: d_k = flag ? d_{k-1} : literal, d_{-1} = 0 per row
 		dv = rlev;
 		if (any(eact & e6)) {

@@ -402,7 +402,8 @@ WV_HD DecLayout make_dec_layout(uint32_t T)
 	L.win = 0;
 	L.img = window_bytes(T) + 32;
 	const uint32_t after = 256 * T + 32;
-	L.total = align16(L.img + (after > max_block_reach(T) ? after : max_block_reach(T)));
+	L.lut = align16(L.img + (after > max_block_reach(T) ? after : max_block_reach(T)));
+	L.total = L.lut + 64;
 	return L;
 }
 
@@ -418,6 +419,7 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 	const uint32_t nblocks = dsize / bs;
 	if (csize < hs + T && nblocks) // block_compress.h:1813-1815
 		return DEC_ERROR;
+	dec_write_lut(lds, L);
 	const uint32_t wcap = window_bytes(T);
 	const uint32_t mis = (uint32_t)((uintptr_t)src & 15u); // the window is filled from the 16-byte aligned address below src
 	const uint8_t* abase = src - mis;
