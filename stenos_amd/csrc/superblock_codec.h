@@ -186,7 +186,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				// they have at most one such plane themselves (a wide batch, slot_codec.h).
 				SlotBatch4 W;
 				W.nblk = 0;
-				if (nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
+				if (B.nslots <= 2 && nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
 					const bool has_d = i + 3 < nblocks;
 					if (!early) {
 						ec = load_raw_block(b + bs, T);
