@@ -869,6 +869,7 @@ size_t so_block_decompress(const uint8_t* src, size_t size, size_t T, size_t byt
 			return SO_ERROR_SRC_OVERFLOW;
 		s += hs;
 		if (*anchor == SO_BLOCK_COPY) {
+			STAT(SO_STAT_COPY_BLOCKS);
 			s = anchor + 1;
 			if ((size_t)(end - s) < bs)
 				return SO_ERROR_SRC_OVERFLOW; /* the reference does not check this */

@@ -88,7 +88,8 @@ enum {
 	SO_STAT_LZ_BLOCKS = 20,
 	SO_STAT_PARTIAL_BLOCKS = 21,
 	SO_STAT_SB_CODE = 22,   /* +0..7 */
-	SO_STAT_COUNT = 30
+	SO_STAT_COPY_BLOCKS = 30, /* [252][raw] blocks (time-limited mode only, block_compress.h:1158-1176) */
+	SO_STAT_COUNT = 32
 };
 size_t so_frame_stats(const void* src, size_t bytesoftype, size_t size, uint64_t counts[SO_STAT_COUNT]);
 

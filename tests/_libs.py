@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ERR_BASE = (1 << 64) - 100
 
-STAT_PLANE_TYPE, STAT_ROW_HDR, STAT_LZ, STAT_PARTIAL, STAT_SB_CODE, STAT_COUNT = 0, 4, 20, 21, 22, 30
+STAT_PLANE_TYPE, STAT_ROW_HDR, STAT_LZ, STAT_PARTIAL, STAT_SB_CODE, STAT_COPY_BLOCKS, STAT_COUNT = 0, 4, 20, 21, 22, 30, 32
 
 
 def has_error(r: int) -> bool:
