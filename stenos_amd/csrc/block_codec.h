@@ -121,33 +121,18 @@ WV_FN void plane_words_from_int16(PlaneRegs& r, const U32& lo, const U32& hi)
 }
 // A block of bytesoftype 2 or 4 straight from HBM into registers, from any byte address (gfx9 and later serve unaligned
 // global accesses in hardware: a slice of an array compresses as fast as the array).
-#ifndef STENOS_NT_SRC
-#define STENOS_NT_SRC 0 // 1: the source blocks are loaded non-temporal
-#endif
-#ifndef STENOS_NT_DST
-#define STENOS_NT_DST 0 // 1: the copier's stores into the frame are non-temporal
-#endif
 struct RawBlock { // the lane's share of a block of bytesoftype 2 (x, y) or 4 (x, y, z, w): its four elements
 	U128 e;
 };
 WV_FN RawBlock load_raw_block(const uint8_t* g, uint32_t T)
 {
 	RawBlock r;
-#if STENOS_NT_SRC
-	if (T == 2) {
-		gld64_stream(g, lane_id() * 8u, r.e.x, r.e.y);
-		r.e.z = r.e.w = U32(0u);
-	}
-	else
-		r.e = gld128_stream(g, lane_id() * 16u);
-#else
 	if (T == 2) {
 		gld64_unaligned(g, lane_id() * 8u, r.e.x, r.e.y);
 		r.e.z = r.e.w = U32(0u);
 	}
 	else
 		r.e = gld128_unaligned(g, lane_id() * 16u, pred_all(true));
-#endif
 	return r;
 }
 WV_FN PlaneRegs plane_regs_of(const RawBlock& b, uint32_t T)

@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint
 // ends.  A poll counter bounds them anyway: a wait that would hang the device is reported as an error instead.
 constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;
 constexpr uint64_t CHAIN_FAILED = ~0ull;
-// A workgroup of the fused kernel: FUSED_WAVES encoder wavefronts and, with FUSED_COPIER, one more wavefront that does
-// nothing but wait for frame offsets and move finished superblocks from the staging streams into the frame.
-#ifndef STENOS_FUSED_COPIER
-#define STENOS_FUSED_COPIER 1
+#ifndef STENOS_FUSED_OCCUPANCY
+#define STENOS_FUSED_OCCUPANCY 8
 #endif
-constexpr uint32_t FUSED_COPIER = STENOS_FUSED_COPIER;
-constexpr uint32_t FUSED_GROUP_WAVES = FUSED_WAVES + FUSED_COPIER;
-constexpr uint32_t FUSED_GROUPS_PER_CU = 32 / FUSED_GROUP_WAVES; // 32 wavefronts per CU, 8 per SIMD: the register allocation is held to that
+constexpr uint32_t FUSED_OCCUPANCY = STENOS_FUSED_OCCUPANCY;
+#ifndef STENOS_FUSED_TICKETS
+#define STENOS_FUSED_TICKETS 0
+#endif
+constexpr uint32_t FUSED_TICKETS = STENOS_FUSED_TICKETS; // superblocks per encoder workgroup; 0: as many as it gets (a resident grid) // waves per SIMD the register allocation of the fused kernel aims at
 
 __device__ inline void chain_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint64_t chain_get(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -164,20 +164,12 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 	return CHAIN_FAILED;
 }
 
-// Workgroup 0: the scanner.  Every other workgroup stays resident and takes superblocks one after the other until none is
-// left.  Its FUSED_WAVES encoder wavefronts each encode a run of consecutive blocks into a staging stream and the
-// workgroup publishes the bytes the superblock takes.  The superblock is moved into the frame one iteration later, while
-// the NEXT one is being encoded into the workgroup's other staging buffer: by then the scanner has normally published its
-// offset.  With FUSED_COPIER that move is the job of a wavefront of its own (fused_store_runs: the only wave that ever polls
-// an offset, with a deep queue of loads since it needs its registers for nothing else), so the encoders go from one
-// superblock straight to the next; without it every encoder wave stores its own run.  A superblock that ends up as a COPY
-// (raw input, four times the bytes of the usual block stream) is stored by all waves together.
-//
-// Barriers per iteration, the same sequence on every path so that every wave meets every barrier: B1 after the ticket (the
-// store of the superblock that used this iteration's staging buffer has ended: whoever did it has arrived), B2 after the
-// encoding (run sizes visible), one more per repeated attempt.
+// Workgroup 0: the scanner.  Every other workgroup: FUSED_WAVES wavefronts that take superblocks one after the other
+// until none is left -- encode (each wave a run of consecutive blocks into its staging stream), publish the size, then
+// store the previous superblock at its offset (pipeline.h, fused_store): by then the scanner has normally passed it.
+// A workgroup owns two staging buffers and alternates between them.
 template <uint32_t TT>
-__global__ __launch_bounds__(64 * FUSED_GROUP_WAVES, 8) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
+__global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
 									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
 {
 	if (blockIdx.x == 0) {
@@ -188,55 +180,42 @@ __global__ __launch_bounds__(64 * FUSED_GROUP_WAVES, 8) void encode_superblocks(
 	const uint32_t T = TT ? TT : j.T;
 	const Layout L = make_layout(T, true);
 	const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const bool copier = FUSED_COPIER && w == FUSED_WAVES;
-	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total); // [parity] ticket, [2] a wait has failed, [8 + 16*parity ..] run sizes
-	uint8_t* const stage_g = stage + ((uint64_t)(blockIdx.x - 1) * 2) * FUSED_WAVES * run_cap; // + (parity * FUSED_WAVES + wave) * run_cap
-	uint32_t b0 = 0, b1 = 0;
-	if (!copier)
-		fused_run_range(j.bps, w, &b0, &b1);
+	volatile uint32_t* shared = (volatile uint32_t*)(g_lds + FUSED_WAVES * L.total); // [parity] ticket, [2] a wait has failed, [8 + 4*parity ..] run sizes
+	uint8_t* const stage_w = stage + (((uint64_t)(blockIdx.x - 1) * 2) * FUSED_WAVES + w) * run_cap; // + parity * FUSED_WAVES * run_cap
+	uint32_t b0, b1;
+	fused_run_range(j.bps, w, &b0, &b1);
 	uint64_t prev = CHAIN_FAILED; // superblock that is encoded but not stored yet
 	uint32_t prev_run[FUSED_WAVES];
-	uint32_t prev_code = 0;
 	bool guess_copy = false; // the workgroup's last superblock ended up as a copy
 	if (threadIdx.x == 0)
 		shared[2] = 0;
-	for (uint32_t it = 0;; ++it) {
+	for (uint32_t it = 0; FUSED_TICKETS == 0 || it <= FUSED_TICKETS; ++it) {
 		const uint32_t parity = it & 1u;
 		if (threadIdx.x == 0)
-			shared[parity] = atomicAdd(ticket, 1u);
-		__syncthreads(); // B1
+			shared[parity] = FUSED_TICKETS && it == FUSED_TICKETS ? 0xFFFFFFFFu : atomicAdd(ticket, 1u);
+		__syncthreads();
 		if (shared[2]) // a wavefront of this workgroup gave up waiting: all leave together (the error is in j.status)
 			return;
 		// readfirstlane yields an int: go through uint32_t or values beyond 2^31 get sign-extended
 		const uint64_t s = (uint32_t)__builtin_amdgcn_readfirstlane(shared[parity]);
 		const bool work = s < nsb;
-		volatile uint32_t* runs = shared + 8 + 16 * parity;
-		uint8_t* const stage_prev = stage_g + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap;
-		if (copier && prev != CHAIN_FAILED && prev_code == 1) { // beside the encoders
-			const uint64_t off = chain_wait(j, prev);
-			if (off == CHAIN_FAILED)
-				shared[2] = 1;
-			else
-				fused_store_runs(j, prev, off, prev_run, stage_prev, run_cap);
-		}
+		volatile uint32_t* runs = shared + 8 + 4 * parity;
 		uint32_t run_size[FUSED_WAVES];
-		uint32_t code = 0;
 		if (work) {
 			// A superblock whose block stream comes out larger than its input is stored as a copy (stenos.cpp:609-610) and
 			// the stream is thrown away: after such a superblock the next one is only measured (nothing written, nothing
 			// staged) and encoded for real only if the guess was wrong.  Incompressible data is incompressible throughout.
 			const uint8_t* from = j.src + (s * j.bps + b0) * (uint64_t)(256 * T);
-			uint8_t* to = stage_g + ((uint64_t)parity * FUSED_WAVES + w) * run_cap;
+			uint8_t* to = stage_w + (uint64_t)parity * FUSED_WAVES * run_cap;
 			for (uint32_t attempt = 0;; ++attempt) {
 				const bool measure = guess_copy && attempt == 0;
-				if (!copier) {
-					const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to);
-					if ((threadIdx.x & 63u) == 0)
-						runs[w] = n;
-				}
-				__syncthreads(); // B2
+				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to);
+				if ((threadIdx.x & 63u) == 0)
+					runs[w] = n;
+				__syncthreads();
 				for (uint32_t k = 0; k < FUSED_WAVES; ++k)
 					run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(runs[k]);
+				uint32_t code;
 				const uint32_t bytes = fused_superblock_size(j, run_size, &code);
 				if (measure && code != 6) { // it does compress: once more, with the bytes
 					__syncthreads(); // (everyone has read the sizes before they are written again)
@@ -249,18 +228,17 @@ __global__ __launch_bounds__(64 * FUSED_GROUP_WAVES, 8) void encode_superblocks(
 			}
 		}
 		else
-			__syncthreads(); // B2
-		if (prev != CHAIN_FAILED && (!FUSED_COPIER || prev_code == 6) && !copier) {
+			__syncthreads();
+		if (prev != CHAIN_FAILED) {
 			const uint64_t off = chain_wait(j, prev);
 			if (off == CHAIN_FAILED)
 				shared[2] = 1;
 			else
-				fused_store(j, prev, w, off, prev_run, stage_prev + (uint64_t)w * run_cap);
+				fused_store(j, prev, w, off, prev_run, stage_w + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap);
 		}
 		if (!work)
 			return;
 		prev = s;
-		prev_code = code;
 		for (uint32_t k = 0; k < FUSED_WAVES; ++k)
 			prev_run[k] = run_size[k];
 	}
@@ -436,12 +414,12 @@ hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1,
 template <uint32_t TT>
 static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
 {
-	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 256;
+	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 64;
 	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
 	const uint32_t grid = stenos_k_fused_groups(nsb) + 1; // + the scanner
-	hipLaunchKernelGGL((encode_superblocks<TT>), dim3(grid), dim3(64 * FUSED_GROUP_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc, ticket, carry);
+	hipLaunchKernelGGL((encode_superblocks<TT>), dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc, ticket, carry);
 	return hipGetLastError();
 }
 
@@ -460,11 +438,13 @@ hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t
 	}
 }
 // the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)
-bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 256 <= 160u * 1024u; }
+bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 64 <= 160u * 1024u; }
 // encoder workgroups of the fused kernel: as many as stay resident (they take superblocks until none is left)
 uint32_t stenos_k_fused_groups(uint64_t nsb)
 {
-	const uint64_t resident = (uint64_t)stenos_k_cu_count() * FUSED_GROUPS_PER_CU;
+	if (FUSED_TICKETS)
+		return (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS);
+	const uint64_t resident = (uint64_t)stenos_k_cu_count() * 8;
 	return (uint32_t)(nsb < resident ? nsb : resident);
 }
 // two staging buffers per workgroup

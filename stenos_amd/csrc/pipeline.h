@@ -240,21 +240,10 @@ WV_FN void resolve_capacity(Lds lds, const Layout& L, const FrameJob& j)
 // by the scanner wavefront of kernels.hip) and every wave copies its own run to its place in the frame.  No
 // per-block table and no separate pack pass.
 #ifndef STENOS_FUSED_WAVES
-#define STENOS_FUSED_WAVES 7
+#define STENOS_FUSED_WAVES 4
 #endif
-constexpr uint32_t FUSED_WAVES = STENOS_FUSED_WAVES; // encoder wavefronts (= runs) per superblock
-// first block of wave w's run: the runs are cut at even block numbers (the slot encoder takes blocks in pairs) and differ
-// by at most two blocks; w == FUSED_WAVES: the end
-WV_HD uint32_t fused_run_start(uint32_t bps, uint32_t w) { return w >= FUSED_WAVES ? bps : (uint32_t)((uint64_t)w * bps / FUSED_WAVES) & ~1u; }
-WV_HD uint32_t fused_run_blocks(uint32_t bps)
-{
-	uint32_t m = 0;
-	for (uint32_t w = 0; w < FUSED_WAVES; ++w) {
-		const uint32_t n = fused_run_start(bps, w + 1) - fused_run_start(bps, w);
-		m = n > m ? n : m;
-	}
-	return m;
-}
+constexpr uint32_t FUSED_WAVES = STENOS_FUSED_WAVES;
+WV_HD uint32_t fused_run_blocks(uint32_t bps) { return (bps + FUSED_WAVES - 1) / FUSED_WAVES; }
 WV_HD uint32_t fused_run_capacity(uint32_t bps, uint32_t T) { return align16(fused_run_blocks(bps) * max_block_bytes(T)) + 64; }
 
 // Number of leading superblocks whose capacity is large enough for any encoding, whatever the sizes of the
@@ -270,8 +259,9 @@ WV_HD uint64_t safe_superblocks(uint64_t dst_size, uint64_t header, uint32_t bps
 // blocks [*b0, *b1) of a superblock are wave w's run
 WV_HD void fused_run_range(uint32_t bps, uint32_t w, uint32_t* b0, uint32_t* b1)
 {
-	*b0 = fused_run_start(bps, w);
-	*b1 = fused_run_start(bps, w + 1);
+	const uint32_t per = fused_run_blocks(bps);
+	*b0 = w * per < bps ? w * per : bps;
+	*b1 = *b0 + per < bps ? *b0 + per : bps;
 }
 
 // BLOCK or COPY and the bytes the superblock takes in the frame (header included), from the run sizes
@@ -313,94 +303,6 @@ WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, 
 		fused_run_range(j.bps, w, &b0, &b1);
 		const uint32_t bs = 256 * j.T;
 		copy_g2g_wide(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
-	}
-}
-
-// The copier wavefront's form of the same store (kernels.hip): ONE wave writes the whole superblock.  The payload of a BLOCK
-// superblock is one contiguous destination range fed by the FUSED_WAVES staging streams, so the copy is laid out over the
-// destination: aligned 16-byte groups, each read with one unaligned 16-byte load from the run that holds it, `ROUNDS`
-// rounds of 64 groups requested before the first store.  The groups cut by a run boundary and the bytes in front of the
-// first / behind the last aligned group (at most FUSED_WAVES + 1 pieces of 16 bytes) follow byte by byte in one more trip.
-// stage0: run 0's stream; run k's stream starts k * run_cap bytes behind it.
-#ifndef STENOS_COPIER_ROUNDS
-#define STENOS_COPIER_ROUNDS 6
-#endif
-constexpr uint32_t COPIER_ROUNDS = STENOS_COPIER_ROUNDS;
-WV_FN void fused_store_runs(const FrameJob& j, uint64_t s, uint64_t off, const uint32_t* run_size, const uint8_t* stage0, uint32_t run_cap)
-{
-	const U32 lane = lane_id_plain();
-	uint32_t code;
-	const uint32_t csize = fused_superblock_size(j, run_size, &code) - 4;
-	uint8_t* base = j.dst + off;
-	if (s == 0 && j.shift_byte != 0xFFFFFFFFu) { // frame header: [shift][bytes:7 LE] (+ [superblock size:4 LE]), stenos.cpp:862-874
-		const uint64_t v = (uint64_t)j.shift_byte | (j.total_bytes << 8);
-		gst8(j.dst, lane, (U32((uint32_t)v) >> ((lane & 3u) << 3)), lane < U32(4u));
-		gst8(j.dst, lane, (U32((uint32_t)(v >> 32)) >> ((lane & 3u) << 3)), (lane >= U32(4u)) & (lane < U32(8u)));
-		if (j.shift_byte == 255)
-			gst8(j.dst + 8, lane, U32(j.sb_bytes) >> ((lane & 3u) << 3), lane < U32(4u));
-	}
-	gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u)); // [code][csize:3 LE] (stenos.cpp:613-615)
-	uint8_t* pay = base + 4;
-	// run k holds payload bytes [before[k], before[k + 1]); byte p of the payload lies at stage0 + p + adj(p),
-	// adj = k * run_cap - before[k] for the run k that holds p
-	uint32_t before[FUSED_WAVES + 1];
-	before[0] = 0;
-	for (uint32_t k = 0; k < FUSED_WAVES; ++k)
-		before[k + 1] = before[k] + run_size[k];
-	auto adj_of = [&](const U32& p) {
-		U32 a(0u);
-		for (uint32_t k = 1; k < FUSED_WAVES; ++k)
-			a = sel(p >= U32(before[k]), U32(k * run_cap - before[k]), a);
-		return a;
-	};
-	const uint32_t head = (uint32_t)((16u - ((uintptr_t)pay & 15u)) & 15u);
-	const uint32_t h = head < csize ? head : csize;
-	const uint32_t groups = (csize - h) >> 4;
-	for (uint32_t o = 0; o < groups; o += 64 * COPIER_ROUNDS) {
-		U128 a[COPIER_ROUNDS];
-		Pred in[COPIER_ROUNDS];
-		for (uint32_t q = 0; q < COPIER_ROUNDS; ++q) {
-			const U32 k = U32(o + 64 * q) + lane;
-			const U32 p = U32(h) + k * 16u;
-			const U32 a0 = adj_of(p);
-			in[q] = (k < U32(groups)) & (a0 == adj_of(p + 15u)); // all 16 bytes in one run
-			a[q] = gld128_unaligned(stage0, p + a0, in[q]);
-		}
-		for (uint32_t q = 0; q < COPIER_ROUNDS; ++q) {
-			const U32 k = U32(o + 64 * q) + lane;
-#if STENOS_NT_DST
-			gst128_stream(pay + h, k * 16u, a[q], in[q]);
-#else
-			gst128(pay + h, k * 16u, a[q], in[q]);
-#endif
-		}
-	}
-	// pieces of 16 bytes handled byte by byte: piece 0 = the head, piece FUSED_WAVES = the tail, piece i = the group that
-	// holds the boundary in front of run i (written twice when it was whole: harmless)
-	for (uint32_t o = 0; o < (FUSED_WAVES + 1) * 16; o += 64) {
-		const U32 idx = U32(o) + lane;
-		const U32 piece = idx >> 4, byte = idx & 15u;
-		U32 start(0u);
-		Pred ok = piece == U32(0u);
-		U32 limit = U32(h);
-		for (uint32_t i = 1; i < FUSED_WAVES; ++i) {
-			const bool has = before[i] >= h && ((before[i] - h) >> 4) < groups;
-			const uint32_t g = has ? (before[i] - h) >> 4 : 0;
-			const Pred me = piece == U32(i);
-			start = sel(me, U32(h + 16 * g), start);
-			limit = sel(me, U32(has ? h + 16 * g + 16 : 0), limit);
-			ok = ok | me;
-		}
-		{
-			const Pred me = piece == U32(FUSED_WAVES);
-			start = sel(me, U32(h + 16 * groups), start);
-			limit = sel(me, U32(csize), limit);
-			ok = ok | me;
-		}
-		const U32 p = start + byte;
-		const Pred w = ok & (p < limit);
-		const U32 ps = sel(w, p, U32(0u));
-		gst8(pay, ps, gld8(stage0, ps + adj_of(ps), w), w);
 	}
 }
 

@@ -407,8 +407,6 @@ WV_FN U128 gld128(const uint8_t* g, const U32& off, const Pred& p) // 16-byte al
 // the same accesses at any byte address
 WV_FN U128 gld128_unaligned(const uint8_t* g, const U32& off, const Pred& p) { return gld128(g, off, p); }
 WV_FN void gld64_unaligned(const uint8_t* g, const U32& off, U32& lo, U32& hi) { gld64(g, off, lo, hi); }
-WV_FN U128 gld128_stream(const uint8_t* g, const U32& off) { return gld128(g, off, pred_all(true)); }
-WV_FN void gld64_stream(const uint8_t* g, const U32& off, U32& lo, U32& hi) { gld64(g, off, lo, hi); }
 WV_FN void gst8(uint8_t* g, const U32& off, const U32& v, const Pred& p)
 {
 	for (int i = 0; i < WAVE; ++i)
@@ -438,7 +436,6 @@ WV_FN void gst128(uint8_t* g, const U32& off, const U128& v, const Pred& p)
 		}
 }
 WV_FN void gst128_unaligned(uint8_t* g, const U32& off, const U128& v, const Pred& p) { gst128(g, off, v, p); }
-WV_FN void gst128_stream(uint8_t* g, const U32& off, const U128& v, const Pred& p) { gst128(g, off, v, p); }
 WV_FN void gst64_unaligned(uint8_t* g, const U32& off, const U32& lo, const U32& hi, const Pred& p) { gst64(g, off, lo, hi, p); }
 // wave-uniform scalar accesses to global memory
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *p; }
@@ -699,30 +696,6 @@ WV_FN U128 gld128_unaligned(const uint8_t* g, U32 off, Pred p)
 		r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
 	}
 	return r;
-}
-// the same for data that is read once (the source array): non-temporal, so that it does not push the lines that ARE read
-// again (the staging streams) out of the caches
-typedef uint32_t wv_u4 __attribute__((ext_vector_type(4)));
-typedef uint32_t wv_u2 __attribute__((ext_vector_type(2)));
-WV_FN U128 gld128_stream(const uint8_t* g, U32 off)
-{
-	typedef wv_u4 __attribute__((aligned(1))) wv_u4_u;
-	wv_u4 v = __builtin_nontemporal_load((const wv_u4_u*)(g + off));
-	U128 r = { v.x, v.y, v.z, v.w };
-	return r;
-}
-WV_FN void gld64_stream(const uint8_t* g, U32 off, U32& lo, U32& hi)
-{
-	typedef wv_u2 __attribute__((aligned(1))) wv_u2_u;
-	wv_u2 v = __builtin_nontemporal_load((const wv_u2_u*)(g + off));
-	lo = v.x;
-	hi = v.y;
-}
-// 16-byte aligned store of data that is not read again (the frame)
-WV_FN void gst128_stream(uint8_t* g, U32 off, const U128& v, Pred p)
-{
-	wv_u4 x = { v.x, v.y, v.z, v.w };
-	if (p) __builtin_nontemporal_store(x, (wv_u4*)(g + off));
 }
 WV_FN void gld64_unaligned(const uint8_t* g, U32 off, U32& lo, U32& hi)
 {

@@ -99,8 +99,6 @@ void emul_dec_layout(size_t T, uint32_t* out)
 }
 static size_t g_last_fused = 0;
 void emul_set_fused(int on) { g_fused = on; }
-static int g_copier = 1; // BLOCK superblocks of the fused zone are stored by fused_store_runs (0: run by run, fused_store)
-void emul_set_copier(int on) { g_copier = on; }
 size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last frame sent through the fused path
 
 size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_t* dst, size_t dst_size, int level)
@@ -198,11 +196,8 @@ size_t emul_compress_frame(const uint8_t* src_in, size_t T, size_t bytes, uint8_
 				break;
 			}
 			sboff[s] = carry; // chain_scanner
-			if (code == 1 && g_copier) // the copier wavefront's store of a whole BLOCK superblock (kernels.hip)
-				fused_store_runs(j, s, carry, run_size, stage + s * FUSED_WAVES * (size_t)run_cap, run_cap);
-			else
-				for (uint32_t w = 0; w < FUSED_WAVES; ++w)
-					fused_store(j, s, w, carry, run_size, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
+			for (uint32_t w = 0; w < FUSED_WAVES; ++w)
+				fused_store(j, s, w, carry, run_size, stage + (s * FUSED_WAVES + w) * (size_t)run_cap);
 			carry += size;
 		}
 		sboff[s_fused] = total = carry;

@@ -211,9 +211,8 @@ def test_slot_rows_encoder_on_plane_mixtures(oracle, emul, T):
             assert r2 == r1 and np.array_equal(out[:r2], f1), (kind, seed)
 
 
-@pytest.mark.parametrize("copier", [1, 0])
 @pytest.mark.parametrize("T", [2, 4, 8])
-def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T, copier):
+def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T):
     """After a superblock that ended up as a copy the fused kernel only measures the next one and encodes it for real when
     it does compress after all (kernels.hip, encode_superblocks): inputs that alternate between noise and compressible
     stretches, cut in and off superblock boundaries."""
@@ -221,8 +220,6 @@ def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T, copier):
 
     emul.emul_set_fused(1)
     emul.emul_set_slots(1)
-    emul.emul_set_copier.argtypes = [c_int]
-    emul.emul_set_copier(copier)  # BLOCK superblocks stored by the copier wavefront's routine (1) or run by run (0)
     emul.emul_compress_frame.restype = c_size_t
     emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
     per = 131072 // (256 * T) * 256
@@ -235,7 +232,6 @@ def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T, copier):
             r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
             assert emul.emul_last_fused() > 0
             assert r2 == r1 and np.array_equal(out[:r2], f1), (pattern, cut)
-    emul.emul_set_copier(1)
 
 
 @pytest.mark.parametrize("T", [65, 100, 128, 132, 508, 512, 516, 1000, 4100])
