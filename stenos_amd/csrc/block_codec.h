@@ -641,6 +641,25 @@ WV_FN void image_reset(Lds lds, const Layout& L, uint32_t base, uint32_t size)
 	}
 }
 
+// The same for the slot encoder (bytesoftype 2 and 4, slot_codec.h): the whole image is cleared by a fixed number of
+// stores and the waiting bytes are always taken over -- no loop, no size arithmetic, no branch in the scalar unit, which is
+// as busy as the vector unit in that encoder.  The 16 bytes in front of the image are zero when nothing waits
+// (stream_begin, stream_append).
+WV_FN void image_reset_fixed(Lds lds, const Layout& L, uint32_t T)
+{
+	const U32 lane = lane_id();
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	const uint32_t bytes = out_capacity(T); // 1088 or 1168: one full store and a partial one
+	lds_st128(lds, U32(L.out) + lane * 16u, z, pred_all(true));
+	lds_st128(lds, U32(L.out + 1024u) + lane * 16u, z, lane * 16u < U32(bytes - 1024u));
+	wave_sync();
+	const Pred p = lane < U32(4u);
+	const U32 a = sel(p, lane, U32(0u)) * 4u;
+	lds_st32(lds, U32(L.out) + a, lds_ld32(lds, U32(L.out - 16u) + a), p);
+	wave_sync();
+}
+
 // ------------------------------------------------------------------------------------------------
 // mini-LZ (lz_compress.h:161-232).  Positions are visited 64 at a time (lane = pos & 63).
 // ------------------------------------------------------------------------------------------------
@@ -689,8 +708,9 @@ WV_HD bool lz_precheck_passes(uint32_t T, uint32_t distinct, uint32_t max_size)
 	const uint32_t B = lz_width(T), nq = lz_precheck_values(T);
 	const uint32_t lower = nq / 8 + nq * B - (nq - distinct) * (B - 1);
 	// the reference compares doubles, lower > max_size * 0.4 (lz_compress.h:226); for these small integers that is
-	// 5 * lower > 2 * max_size: the product is exact when max_size is a multiple of 5 and at least 0.2 away from an integer otherwise
-	return !(lower > max_size || 5 * lower > 2 * max_size);
+	// 5 * lower > 2 * max_size: the product is exact when max_size is a multiple of 5 and at least 0.2 away from an integer otherwise.
+	// (Its other test, lower > max_size (:221-223), is implied: it would make 5 * lower > 5 * max_size.)
+	return !(5 * lower > 2 * max_size);
 }
 // distinct hash keys among the first nq values of the block at L.in; uses the first KiB of the image (not L.lz)
 WV_FN uint32_t lz_distinct_keys(Lds lds, const Layout& L, uint32_t T)

@@ -38,9 +38,9 @@ WV_FN SameScan scan_same_fast(const RawBlock& b, uint32_t T)
 		x = ((b.e.x ^ e) | (b.e.y ^ e)) | ((b.e.z ^ e) | (b.e.w ^ e));
 		s.first = e0;
 	}
-	s.act = mask_nonzero(ballot((x & 0xFFu) != U32(0u))) | (mask_nonzero(ballot((x & 0xFF00u) != U32(0u))) << 1);
+	s.act = mask_bit<1>(ballot((x & 0xFFu) != U32(0u))) | mask_bit<2>(ballot((x & 0xFF00u) != U32(0u)));
 	if (T == 4)
-		s.act |= (mask_nonzero(ballot((x & 0xFF0000u) != U32(0u))) << 2) | (mask_nonzero(ballot((x & 0xFF000000u) != U32(0u))) << 3);
+		s.act |= mask_bit<4>(ballot((x & 0xFF0000u) != U32(0u))) | mask_bit<8>(ballot((x & 0xFF000000u) != U32(0u)));
 	s.nact = (uint32_t)__builtin_popcount(s.act);
 	return s;
 }

@@ -83,7 +83,11 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 	const uint32_t r = rs.pos & 15u;
 	const uint32_t groups = (r + n) >> 4;
 	uint8_t* g = rs.base + (rs.pos - r);
-	for (uint32_t o = 0; o < groups; o += 64) {
+	{ // the first 64 groups without a loop around them: that is all of them unless the blocks hardly compress
+		Pred p = lane < U32(groups);
+		gst128(g, lane * 16u, lds_ld128(lds, U32(out) + sel(p, lane, U32(0u)) * 16u), p);
+	}
+	for (uint32_t o = 64; o < groups; o += 64) {
 		U32 k = U32(o) + lane;
 		Pred p = k < U32(groups);
 		gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
@@ -95,6 +99,14 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 	lds_st32(lds, U32(out - 16u) + a, v, t);
 	wave_sync();
 	rs.pos += n;
+}
+// nothing waits at the start of a stream
+WV_FN void stream_begin(Lds lds, uint32_t out)
+{
+	const U32 lane = lane_id();
+	Pred t = lane < U32(4u);
+	lds_st32(lds, U32(out - 16u) + sel(t, lane, U32(0u)) * 4u, U32(0u), t);
+	wave_sync();
 }
 WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 {
@@ -155,6 +167,27 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 				was_wide = false;
 				WV_MARK("block_begin");
+#if defined(STENOS_PAD_CHEAP) || defined(STENOS_PAD_OTHER) || defined(STENOS_PAD_SALU)
+				{ // timing experiments only (tools/build_variant.sh): what an instruction of each class costs at the margin
+					uint32_t padv = 1, pads = 1;
+#ifdef STENOS_PAD_CHEAP
+#pragma unroll
+					for (int q = 0; q < STENOS_PAD_CHEAP; ++q)
+						asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(padv));
+#endif
+#ifdef STENOS_PAD_OTHER
+#pragma unroll
+					for (int q = 0; q < STENOS_PAD_OTHER; ++q)
+						asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(padv));
+#endif
+#ifdef STENOS_PAD_SALU
+#pragma unroll
+					for (int q = 0; q < STENOS_PAD_SALU; ++q)
+						asm volatile("s_add_u32 %0, %0, 1" : "+s"(pads) : : "scc");
+#endif
+					asm volatile("" : : "v"(padv), "s"(pads));
+				}
+#endif
 				const Layout M = sink.at(L);
 				SlotBatch B;
 				uint32_t keys0 = 0, keys1 = 0; // distinct hash keys among the first 40 values of each block (first rejection test of the mini-LZ)
@@ -165,13 +198,16 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					B.nact0 = B.nslots = sa.nact;
 					B.act[1] = B.first[1] = 0;
 				}
-				if (has_b && B.nact0 <= 2) {
-					const SameScan sb = scan_same_fast(eb, T);
-					if (B.nact0 + sb.nact <= 4) {
-						B.act[1] = sb.act;
-						B.first[1] = sb.first;
-						B.nslots = B.nact0 + sb.nact;
-						nblk = 2;
+				if (has_b) {
+					WV_NESTED();
+					if (B.nact0 <= 2) {
+						const SameScan sb = scan_same_fast(eb, T);
+						if (B.nact0 + sb.nact <= 4) {
+							B.act[1] = sb.act;
+							B.first[1] = sb.first;
+							B.nslots = B.nact0 + sb.nact;
+							nblk = 2;
+						}
 					}
 				}
 								if (T == 4 && B.nact0 >= 2) // with fewer non-constant planes the block is too small for the mini-LZ (:1210)
@@ -186,7 +222,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				// they have at most one such plane themselves (a wide batch, slot_codec.h).
 				SlotBatch4 W;
 				W.nblk = 0;
-				if (B.nslots <= 2 && nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
+				if (B.nslots <= 2) { WV_NESTED(); if (nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
 					const bool has_d = i + 3 < nblocks;
 					if (!early) {
 						ec = load_raw_block(b + bs, T);
@@ -213,7 +249,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 						nblk = W.nblk;
 						was_wide = true;
 					}
-				}
+				} }
 				wave_sync();
 				if (W.nblk) {
 					SlotRows R;
@@ -230,7 +266,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					const SlotPlace P = slot_rows_place4(R, W, T, hs, sink.base(), base, &bbase);
 					const uint32_t total = base[3] + (W.nblk > 3 ? hs + W.full[3] : 0u) - base[0];
 					if (sink.writes) {
-						image_reset(lds, M, base[0], total);
+						image_reset_fixed(lds, M, T);
 						slot_rows_emit4(lds, M, T, R, P, W, bbase, base);
 					}
 					sink.append(lds, M, total);
@@ -268,7 +304,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					const uint32_t base = sink.base(), size0 = hs + B.full[0], size1 = nblk > 1 ? hs + B.full[1] : 0u;
 					if (sink.writes) {
 						WV_MARK("image_reset");
-						image_reset(lds, M, base, size0 + size1);
+						image_reset_fixed(lds, M, T);
 						slot_rows_emit(lds, M, T, R, P, B, base, base + size0);
 					}
 					WV_MARK("stream_append");
@@ -307,6 +343,8 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 	sink.rs.base = stage;
 	sink.rs.pos = 0;
 	sink.writes = stage != nullptr;
+	if (sink.writes)
+		stream_begin(lds, L.out);
 	encode_blocks_to(sink, lds, L, T, src, nblocks, slots);
 	if (sink.writes)
 		stream_flush(sink.rs, lds, L.out);

@@ -23,6 +23,7 @@
 #define WV_MFN inline
 #define WV_HD static inline
 #define WV_MARK(name)
+#define WV_NESTED()
 namespace wv {
 constexpr int WAVE = 64;
 
@@ -231,6 +232,8 @@ WV_FN uint64_t ballot(const Pred& p)
 WV_FN uint32_t readlane(const U32& a, uint32_t lane) { return a.l[lane & 63]; }
 // 1 when the lane mask is not empty, else 0
 WV_FN uint32_t mask_nonzero(uint64_t m) { return m ? 1u : 0u; }
+template <uint32_t BIT>
+WV_FN uint32_t mask_bit(uint64_t m) { return m ? BIT : 0u; }
 // lane i reads a[src[i] & 63]
 WV_FN U32 shfl(const U32& a, const U32& src)
 {
@@ -481,6 +484,10 @@ WV_FN void lds_st128(Lds m, const U32& a, const U128& v, const Pred& p)
 #define WV_HD static __host__ __device__ __forceinline__
 // a comment line in the generated ISA (tools/isa_regions.py counts the instructions between marks); no code
 #define WV_MARK(name) asm volatile("; MARK " name)
+// At the start of a block guarded by a wave-uniform condition: keeps the compiler from folding that condition into the
+// conditions tested inside the block (it evaluates "a && b && c" of cheap scalar terms without branches: three scalar
+// instructions per term on every pass, where the first test alone usually decides).  No code.
+#define WV_NESTED() asm volatile("")
 namespace wv {
 constexpr int WAVE = 64;
 typedef uint32_t U32;
@@ -527,6 +534,14 @@ WV_FN uint32_t mask_nonzero(uint64_t m)
 {
 	uint32_t r;
 	asm("s_bcnt1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, 1" : "=s"(r) : "s"(m) : "scc");
+	return r;
+}
+// `bit` when the lane mask is not empty, else 0 (bit: a constant): a compare and a select in the scalar unit
+template <uint32_t BIT>
+WV_FN uint32_t mask_bit(uint64_t m)
+{
+	uint32_t r;
+	asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(r) : "s"(m), "i"(BIT) : "scc");
 	return r;
 }
 WV_FN U32 shfl(U32 a, U32 src) { return (U32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)a); }
