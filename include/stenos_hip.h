@@ -57,6 +57,14 @@ STENOS_EXPORT size_t stenos_hip_unshuffle(const void* d_src, size_t bytesoftype,
 STENOS_EXPORT size_t stenos_hip_delta(const void* d_src, void* d_dst, size_t bytes, void* stream);
 STENOS_EXPORT size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t bytes, void* stream);
 
+/* Host-pointer calls on several devices.  stenos_set_threads(ctx, n) (stenos.h) says how many DEVICES -- PCIe links -- a
+ * stenos_compress_generic / stenos_decompress_generic call with host pointers may use (the codec itself is an order of
+ * magnitude faster than one link): from 64 MiB on, at level 0/1 with bytesoftype > 1, every device takes a contiguous
+ * range of superblocks through a context and a host thread of its own, starting with the calling thread's current
+ * device; frames are byte-identical to single-device frames.  The environment variable STENOS_HIP_DEVICES caps the
+ * number.  This call returns how many devices the last host-pointer call on ctx used (1: the single-device path). */
+STENOS_EXPORT int stenos_hip_last_devices(stenos_context* ctx);
+
 /* Kernel timing for benchmarks: when enabled, HIP events are recorded on the job's stream around the
  * dominant kernel of each direction: which = 0, the encoder (encode_superblocks, the fused kernel; encode_blocks
  * where that one does not apply), which = 1, decode_superblocks.  stenos_hip_kernel_ms returns the elapsed

@@ -207,13 +207,46 @@ struct stenos_context_s {
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; // encode start/stop, decode start/stop
 	bool ev_valid[2] = { false, false };
 	hipStream_t up_stream = nullptr, main_stream = nullptr; // chunked host-pointer calls: uploads / coding + downloads
+	int last_devices = 1; // devices the last host-pointer call used
+	int device = -1; // the device the buffers above live on (the one that was current when they were first needed)
+	// host-pointer calls with stenos_set_threads(ctx, n > 1): one child context per further device (or per stand-in lane),
+	// used from a host thread of its own (multi_device below)
+	std::vector<stenos_context_s*> lanes;
 
+	void release_device_state()
+	{
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide };
+		for (DevBuf* b : all)
+			b->release();
+		if (h_total)
+			(void)hipHostFree(h_total);
+		h_total = nullptr;
+		for (hipEvent_t& e : ev)
+			if (e) {
+				(void)hipEventDestroy(e);
+				e = nullptr;
+			}
+		ev_valid[0] = ev_valid[1] = false;
+		for (hipStream_t* s : { &up_stream, &main_stream })
+			if (*s) {
+				(void)hipStreamDestroy(*s);
+				*s = nullptr;
+			}
+		last_nsb = 0;
+		job_kind = 0;
+	}
 	bool device_ready()
 	{
+		int cur = -1;
+		if (probed && usable && hipGetDevice(&cur) == hipSuccess && cur != device) {
+			// the caller switched devices between calls: buffers of the old device are of no use on this one
+			release_device_state();
+			probed = false;
+		}
 		if (!probed) {
 			probed = true;
 			int n = 0;
-			usable = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+			usable = hipGetDeviceCount(&n) == hipSuccess && n > 0 && hipGetDevice(&device) == hipSuccess;
 			if (usable && hipHostMalloc((void**)&h_total, 64, hipHostMallocDefault) != hipSuccess)
 				usable = false;
 		}
@@ -221,6 +254,11 @@ struct stenos_context_s {
 	}
 	~stenos_context_s()
 	{
+		for (stenos_context_s* l : lanes)
+			if (l) {
+				l->~stenos_context_s();
+				free(l);
+			}
 		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide };
 		for (DevBuf* b : all)
 			b->release();
@@ -1254,8 +1292,10 @@ inline bool chunk_streams(stenos_context_s* ctx)
 	return true;
 }
 
-size_t compress_chunked(stenos_context_s* ctx, const uint8_t* src, size_t T, size_t bytes, uint8_t* out, size_t dst_size, const FramePlan& f)
+// *no_thread: the helper thread could not be started and nothing has been done (the caller takes the single pass)
+size_t compress_chunked(stenos_context_s* ctx, const uint8_t* src, size_t T, size_t bytes, uint8_t* out, size_t dst_size, const FramePlan& f, bool* no_thread)
 {
+	*no_thread = false;
 	const size_t chunk = kHostChunkBytes / f.sb * f.sb;
 	const size_t chunks = (bytes + chunk - 1) / chunk;
 	const size_t worst = f.header + (chunk / f.sb) * 4 + chunk; // a chunk stored as copies
@@ -1267,8 +1307,10 @@ size_t compress_chunked(stenos_context_s* ctx, const uint8_t* src, size_t T, siz
 	if (!up.start(chunks, [=](size_t k) {
 		    const size_t begin = k * chunk, n = bytes - begin < chunk ? bytes - begin : chunk;
 		    return hipMemcpyAsync(d_in + begin, src + begin, n, hipMemcpyHostToDevice, up_stream) == hipSuccess && hipStreamSynchronize(up_stream) == hipSuccess;
-	    }))
+	    })) {
+		*no_thread = true;
 		return STENOS_ERROR_ALLOC;
+	}
 	out[0] = (uint8_t)f.shift;
 	put_le(out + 1, bytes, 7);
 	if (f.header == 12)
@@ -1292,23 +1334,29 @@ size_t compress_chunked(stenos_context_s* ctx, const uint8_t* src, size_t T, siz
 	return off;
 }
 
-// h_index: offsets of the superblock headers in the frame and its end (walked by the caller); only codes 1 and 6 inside
-size_t decompress_chunked(stenos_context_s* ctx, const uint8_t* in, size_t T, const FrameInfo& fi, const std::vector<uint64_t>& h_index, uint8_t* out)
+// h_index: offsets of the superblock headers in the frame and its end (walked by the caller); only codes 1 and 6 inside.
+// Superblocks [sA, sB) of the frame -> their bytes of `out`.
+size_t decompress_chunked(stenos_context_s* ctx, const uint8_t* in, size_t T, const FrameInfo& fi, const std::vector<uint64_t>& h_index, uint8_t* out, uint64_t sA,
+			  uint64_t sB, bool* no_thread = nullptr)
 {
+	if (no_thread)
+		*no_thread = false;
 	const uint64_t per = kHostChunkBytes / fi.sb ? kHostChunkBytes / fi.sb : 1; // superblocks per chunk
-	const size_t chunks = (size_t)((fi.nsb + per - 1) / per);
-	const size_t size = (size_t)h_index[fi.nsb];
-	// chunk k on the device: [frame header of its own][its superblocks], 16 bytes further than in the frame per chunk
-	// before it so that the headers do not overlap the neighbours; its index in sboff at entry s0 + k
-	if (!chunk_streams(ctx) || !ctx->in.ensure(size + 16 * (chunks + 1) + 64) || !ctx->out.ensure((size_t)fi.total + 64) || !ctx->sboff.ensure((fi.nsb + chunks + 2) * 8))
-		return STENOS_ERROR_ALLOC;
+	const uint64_t count = sB - sA;
+	const size_t chunks = (size_t)((count + per - 1) / per);
+	const size_t size = (size_t)(h_index[sB] - h_index[sA]);
+	const uint64_t oA = sA * fi.sb, oB = sB * fi.sb < fi.total ? sB * fi.sb : fi.total;
 	const size_t H = fi.header; // 8, or 12 with a custom superblock size (repeated in every chunk's header)
-	std::vector<uint64_t> rel(fi.nsb + chunks);
+	// chunk k on the device: [frame header of its own][its superblocks], 16 bytes further than in the frame per chunk
+	// before it so that the headers do not overlap the neighbours; its index in sboff at entry (s0 - sA) + k
+	if (!chunk_streams(ctx) || !ctx->in.ensure(size + 16 * (chunks + 1) + H + 64) || !ctx->out.ensure((size_t)(oB - oA) + 64) || !ctx->sboff.ensure((count + chunks + 2) * 8))
+		return STENOS_ERROR_ALLOC;
+	std::vector<uint64_t> rel(count + chunks);
 	std::vector<uint8_t> hdr(12 * chunks);
 	for (size_t k = 0; k < chunks; ++k) {
-		const uint64_t s0 = k * per, s1 = s0 + per < fi.nsb ? s0 + per : fi.nsb;
+		const uint64_t s0 = sA + k * per, s1 = s0 + per < sB ? s0 + per : sB;
 		for (uint64_t s = s0; s <= s1; ++s)
-			rel[s + k] = h_index[s] - h_index[s0] + H;
+			rel[s - sA + k] = h_index[s] - h_index[s0] + H;
 		const uint64_t o0 = s0 * fi.sb, o1 = s1 * fi.sb < fi.total ? s1 * fi.sb : fi.total;
 		memcpy(&hdr[12 * k], in, H);
 		put_le(&hdr[12 * k + 1], o1 - o0, 7);
@@ -1319,25 +1367,27 @@ size_t decompress_chunked(stenos_context_s* ctx, const uint8_t* in, size_t T, co
 	const uint64_t* idx = h_index.data();
 	const uint64_t* relp = rel.data();
 	const uint8_t* hdrp = hdr.data();
-	const uint64_t nsb = fi.nsb;
-	auto chunk_frame = [=](size_t k) { return d_in + idx[k * per] + 16 * (k + 1) - H; };
+	auto chunk_frame = [=](size_t k) { return d_in + (idx[sA + k * per] - idx[sA]) + 16 * (k + 1); };
 	Uploader up;
 	if (!up.start(chunks, [=](size_t k) {
-		    const uint64_t s0 = k * per, s1 = s0 + per < nsb ? s0 + per : nsb;
+		    const uint64_t s0 = sA + k * per, s1 = s0 + per < sB ? s0 + per : sB;
 		    uint8_t* d = chunk_frame(k);
 		    return hipMemcpyAsync(d, hdrp + 12 * k, H, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
 			   hipMemcpyAsync(d + H, in + idx[s0], idx[s1] - idx[s0], hipMemcpyHostToDevice, up_stream) == hipSuccess &&
-			   hipMemcpyAsync(d_rel + s0 + k, relp + s0 + k, (s1 - s0 + 1) * 8, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
+			   hipMemcpyAsync(d_rel + (s0 - sA) + k, relp + (s0 - sA) + k, (s1 - s0 + 1) * 8, hipMemcpyHostToDevice, up_stream) == hipSuccess &&
 			   hipStreamSynchronize(up_stream) == hipSuccess;
-	    }))
+	    })) {
+		if (no_thread)
+			*no_thread = true;
 		return STENOS_ERROR_ALLOC;
+	}
 	for (size_t k = 0; k < chunks; ++k) {
 		if (!up.wait_for(k))
 			return STENOS_ERROR_UNDEFINED;
-		const uint64_t s0 = k * per, s1 = s0 + per < fi.nsb ? s0 + per : fi.nsb;
+		const uint64_t s0 = sA + k * per, s1 = s0 + per < sB ? s0 + per : sB;
 		const uint64_t o0 = s0 * fi.sb, o1 = s1 * fi.sb < fi.total ? s1 * fi.sb : fi.total;
-		uint8_t* d_out = ctx->out.as<uint8_t>() + o0;
-		const size_t r = decompress_device(ctx, chunk_frame(k), T, (size_t)(H + h_index[s1] - h_index[s0]), d_out, (size_t)(o1 - o0), d_rel + s0 + k, nullptr, nullptr,
+		uint8_t* d_out = ctx->out.as<uint8_t>() + (o0 - oA);
+		const size_t r = decompress_device(ctx, chunk_frame(k), T, (size_t)(H + h_index[s1] - h_index[s0]), d_out, (size_t)(o1 - o0), d_rel + (s0 - sA) + k, nullptr, nullptr,
 						   stream, true);
 		if (is_err(r))
 			return r;
@@ -1346,6 +1396,216 @@ size_t decompress_chunked(stenos_context_s* ctx, const uint8_t* in, size_t T, co
 		if (hipMemcpyAsync(out + o0, d_out, (size_t)(o1 - o0), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 	}
+	return (size_t)(oB - oA);
+}
+
+// ---- host-pointer calls on page-locked memory ---------------------------------------------------------
+// Memory the caller has page-locked (hipHostMalloc, hipHostRegister, a pinned tensor) is visible to the device: the
+// kernels then read the input and write the frame THROUGH the link, both directions at once, with no staging copy on
+// either side -- the call is bound by the larger of the two transfers instead of their sum.  Returns the device alias of
+// [p, p + n) or NULL (pageable memory, or a range that leaves its registration).
+void* device_alias(const void* p, size_t n)
+{
+	hipPointerAttribute_t a;
+	if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) {
+		(void)hipGetLastError(); // (pageable memory is "invalid value" to the runtime)
+		return nullptr;
+	}
+	if (a.type != hipMemoryTypeHost || !a.devicePointer)
+		return nullptr;
+	void* base = nullptr;
+	size_t size = 0;
+	if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	const uintptr_t lo = (uintptr_t)a.devicePointer, end = (uintptr_t)base + size;
+	return lo >= (uintptr_t)base && lo + n <= end ? a.devicePointer : nullptr;
+}
+
+// ---- host-pointer calls on several devices ------------------------------------------------------------
+// The reference's dispatcher hands superblocks to the threads of stenos_set_threads (stenos.cpp:909-1010, 1151-1202).
+// Here a host-pointer call is bound by the PCIe link of the device, not by the codec, so the same knob says how many
+// DEVICES -- how many links -- a call may use: superblocks are independent in both directions, every device takes a
+// contiguous range of them through a child context driven by a host thread of its own, and nothing is exchanged between
+// devices (no collective: the caller's buffers are the meeting point).
+//   compress:   every device uploads and encodes its range (a frame of its own, roomy destination); the sizes meet on
+//               the host, a prefix sum gives every range its place and each device downloads straight to it.  Only
+//               superblocks whose encoding cannot depend on the room that is left (safe_superblocks) are shared out; the
+//               last one or two of a frame -- or all of them under a tight dst_size -- follow on the calling thread's
+//               device with the exact room, as in the single-device path.
+//   decompress: the host walks the superblock headers anyway; every device gets a range of them and writes its bytes.
+// STENOS_HIP_DEVICES=n caps the devices used; STENOS_HIP_LANES_ON_ONE_DEVICE=1 (tests on a one-GPU box) lets the lanes
+// share the current device.
+constexpr size_t kLanesFrom = (size_t)64 << 20; // below, one link moves the data before a second thread is up
+
+int lane_count(stenos_context_s* ctx, size_t bytes)
+{
+	if (ctx->threads <= 1 || bytes < kLanesFrom)
+		return 1;
+	static const int cap = [] {
+		const char* e = getenv("STENOS_HIP_DEVICES");
+		return e ? atoi(e) : 0;
+	}();
+	static const bool one = [] {
+		const char* e = getenv("STENOS_HIP_LANES_ON_ONE_DEVICE");
+		return e && e[0] == '1';
+	}();
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+		return 1;
+	if (one)
+		n = 8;
+	if (cap > 0 && n > cap)
+		n = cap;
+	return n < ctx->threads ? n : ctx->threads;
+}
+// lane 0 is the context itself (the calling thread's device); lane i > 0 a child on device (current + i) % count
+stenos_context_s* lane_context(stenos_context_s* ctx, int i, int* device)
+{
+	static const bool one = [] {
+		const char* e = getenv("STENOS_HIP_LANES_ON_ONE_DEVICE");
+		return e && e[0] == '1';
+	}();
+	int cur = 0, n = 1;
+	(void)hipGetDevice(&cur);
+	(void)hipGetDeviceCount(&n);
+	*device = one ? cur : (cur + i) % (n > 0 ? n : 1);
+	if (i == 0)
+		return ctx;
+	if ((int)ctx->lanes.size() < i)
+		ctx->lanes.resize((size_t)i, nullptr);
+	stenos_context_s*& l = ctx->lanes[(size_t)i - 1];
+	if (!l) {
+		void* m = malloc(sizeof(stenos_context_s));
+		if (!m)
+			return nullptr;
+		l = new (m) stenos_context_s();
+	}
+	l->level = ctx->level;
+	l->threads = 1;
+	l->max_nanoseconds = 0;
+	l->custom_shift = ctx->custom_shift;
+	return l;
+}
+// runs fn(i) for every lane on a thread of its own (lane 0 on the calling thread) with the lane's device current
+bool run_lanes(int n, const std::vector<int>& device, const std::function<void(int)>& fn)
+{
+	std::vector<std::thread> th;
+	bool ok = true;
+	for (int i = 1; i < n; ++i) {
+		try {
+			th.emplace_back([&, i] {
+				if (hipSetDevice(device[(size_t)i]) == hipSuccess)
+					fn(i);
+			});
+		}
+		catch (...) {
+			ok = false;
+			break;
+		}
+	}
+	if (ok)
+		fn(0);
+	for (std::thread& t : th)
+		t.join();
+	return ok;
+}
+
+size_t compress_lanes(stenos_context_s* ctx, const uint8_t* src, size_t T, size_t bytes, uint8_t* out, size_t dst_size, const FramePlan& f, int n)
+{
+	// superblocks that are coded the same whatever room is left, all of them full: these are shared out
+	uint64_t safe = codec::safe_superblocks(dst_size, f.header, f.bps, (uint32_t)T, f.sb, f.nsb);
+	const uint64_t whole = f.nfull / f.bps;
+	safe = safe < whole ? safe : whole;
+	if (safe < (uint64_t)(2 * n))
+		return STENOS_ERROR_INVALID_PARAMETER; // (not an error: the caller takes the single-device path)
+	std::vector<stenos_context_s*> lane((size_t)n);
+	std::vector<int> device((size_t)n);
+	for (int i = 0; i < n; ++i)
+		if (!(lane[(size_t)i] = lane_context(ctx, i, &device[(size_t)i])))
+			return STENOS_ERROR_ALLOC;
+	std::vector<size_t> got((size_t)n, 0);
+	auto range = [&](int i, uint64_t* a, uint64_t* b) {
+		*a = safe * (uint64_t)i / (uint64_t)n;
+		*b = safe * (uint64_t)(i + 1) / (uint64_t)n;
+	};
+	// upload + encode
+	if (!run_lanes(n, device, [&](int i) {
+		    stenos_context_s* c = lane[(size_t)i];
+		    uint64_t a, b;
+		    range(i, &a, &b);
+		    const size_t nb = (size_t)(b - a) * f.sb, worst = f.header + (size_t)(b - a) * 4 + nb + 4096;
+		    if (!c->device_ready() || !chunk_streams(c) || !c->in.ensure(nb + 64) || !c->out.ensure(worst + 64)) {
+			    got[(size_t)i] = STENOS_ERROR_ALLOC;
+			    return;
+		    }
+		    if (hipMemcpyAsync(c->in.p, src + a * f.sb, nb, hipMemcpyHostToDevice, c->main_stream) != hipSuccess) {
+			    got[(size_t)i] = STENOS_ERROR_UNDEFINED;
+			    return;
+		    }
+		    got[(size_t)i] = compress_device(c, c->in.p, T, nb, c->out.p, worst, c->main_stream, true);
+	    }))
+		return STENOS_ERROR_ALLOC;
+	std::vector<size_t> off((size_t)n + 1);
+	off[0] = f.header;
+	for (int i = 0; i < n; ++i) {
+		if (is_err(got[(size_t)i]))
+			return got[(size_t)i];
+		off[(size_t)i + 1] = off[(size_t)i] + got[(size_t)i] - f.header;
+	}
+	if (off[(size_t)n] > dst_size)
+		return STENOS_ERROR_DST_OVERFLOW; // (cannot happen for safe superblocks; never write past the buffer)
+	// download, every range to its place
+	std::vector<int> bad((size_t)n, 0);
+	run_lanes(n, device, [&](int i) {
+		stenos_context_s* c = lane[(size_t)i];
+		if (hipMemcpyAsync(out + off[(size_t)i], c->out.as<uint8_t>() + f.header, got[(size_t)i] - f.header, hipMemcpyDeviceToHost, c->main_stream) != hipSuccess ||
+		    hipStreamSynchronize(c->main_stream) != hipSuccess)
+			bad[(size_t)i] = 1;
+	});
+	for (int b : bad)
+		if (b)
+			return STENOS_ERROR_UNDEFINED;
+	out[0] = (uint8_t)f.shift;
+	put_le(out + 1, bytes, 7);
+	if (f.header == 12)
+		put_le(out + 8, f.sb, 4);
+	size_t end = off[(size_t)n];
+	if (safe < f.nsb) { // the superblocks that look at the room: one more frame, with exactly the room the caller's buffer has left
+		const size_t begin = (size_t)safe * f.sb, rest = bytes - begin;
+		const size_t room = dst_size - end + f.header, worst = f.header + (size_t)(f.nsb - safe) * 4 + rest;
+		if (!ctx->in.ensure(rest + 64) || !ctx->out.ensure((room < worst ? room : worst) + 64))
+			return STENOS_ERROR_ALLOC;
+		if (hipMemcpy(ctx->in.p, src + begin, rest, hipMemcpyHostToDevice) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		const size_t r = compress_device(ctx, ctx->in.p, T, rest, ctx->out.p, room, nullptr, true);
+		if (is_err(r))
+			return r;
+		if (hipMemcpy(out + end, ctx->out.as<uint8_t>() + f.header, r - f.header, hipMemcpyDeviceToHost) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		end += r - f.header;
+	}
+	return end;
+}
+
+size_t decompress_lanes(stenos_context_s* ctx, const uint8_t* in, size_t T, const FrameInfo& fi, const std::vector<uint64_t>& h_index, uint8_t* out, int n)
+{
+	std::vector<stenos_context_s*> lane((size_t)n);
+	std::vector<int> device((size_t)n);
+	for (int i = 0; i < n; ++i)
+		if (!(lane[(size_t)i] = lane_context(ctx, i, &device[(size_t)i])))
+			return STENOS_ERROR_ALLOC;
+	std::vector<size_t> got((size_t)n, 0);
+	if (!run_lanes(n, device, [&](int i) {
+		    const uint64_t a = fi.nsb * (uint64_t)i / (uint64_t)n, b = fi.nsb * (uint64_t)(i + 1) / (uint64_t)n;
+		    stenos_context_s* c = lane[(size_t)i];
+		    got[(size_t)i] = !c->device_ready() ? (size_t)STENOS_ERROR_INVALID_INSTRUCTION_SET : (a < b ? decompress_chunked(c, in, T, fi, h_index, out, a, b) : 0);
+	    }))
+		return STENOS_ERROR_ALLOC;
+	for (size_t r : got)
+		if (is_err(r))
+			return r;
 	return (size_t)fi.total;
 }
 
@@ -1528,8 +1788,41 @@ size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t byte
 	// the largest frame there can be: every superblock stored as a copy.  (stenos_bound() assumes superblocks of the
 	// default size; with stenos_set_block_size() there can be many more headers.)  Nothing is written past dst_size.
 	const size_t worst = f.header + f.nsb * 4 + bytes;
-	if (bytes >= kHostChunkedFrom && !needs_strategy(bytesoftype, ctx->level))
-		return compress_chunked(ctx, (const uint8_t*)src, bytesoftype, bytes, out, dst_size, f);
+	if (!needs_strategy(bytesoftype, ctx->level)) {
+		const int lanes = lane_count(ctx, bytes);
+		ctx->last_devices = 1;
+		if (lanes > 1) {
+			const size_t r = compress_lanes(ctx, (const uint8_t*)src, bytesoftype, bytes, out, dst_size, f, lanes);
+			if (r != STENOS_ERROR_INVALID_PARAMETER) { // (that one: too few shareable superblocks, e.g. a tight dst_size)
+				ctx->last_devices = lanes;
+				return r;
+			}
+		}
+	}
+	if (!needs_strategy(bytesoftype, ctx->level)) {
+		// page-locked caller memory: no staging on that side (both sides: no copy at all)
+		void* a_src = device_alias(src, bytes);
+		void* a_dst = device_alias(dst, dst_size);
+		if (a_src || a_dst) {
+			const size_t cap = dst_size < worst ? dst_size : worst;
+			if ((!a_src && !ctx->in.ensure(bytes + 64)) || (!a_dst && !ctx->out.ensure(cap + 64)))
+				return STENOS_ERROR_ALLOC;
+			if (!a_src && hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			const size_t r = compress_device(ctx, a_src ? a_src : ctx->in.p, bytesoftype, bytes, a_dst ? a_dst : ctx->out.p, dst_size, nullptr, true);
+			if (is_err(r))
+				return r;
+			if (!a_dst && hipMemcpy(dst, ctx->out.p, r, hipMemcpyDeviceToHost) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			return r;
+		}
+	}
+	if (bytes >= kHostChunkedFrom && !needs_strategy(bytesoftype, ctx->level)) {
+		bool no_thread = false;
+		const size_t r = compress_chunked(ctx, (const uint8_t*)src, bytesoftype, bytes, out, dst_size, f, &no_thread);
+		if (!no_thread)
+			return r;
+	}
 	if (!ctx->in.ensure(bytes + 64) || !ctx->out.ensure((dst_size < worst ? dst_size : worst) + 64))
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
@@ -1607,8 +1900,38 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	}
 	if (!ctx->device_ready())
 		return STENOS_ERROR_INVALID_INSTRUCTION_SET;
-	if (fi.total >= kHostChunkedFrom && !host_codes)
-		return decompress_chunked(ctx, in, bytesoftype, fi, index, out);
+	if (!host_codes) {
+		const int lanes = lane_count(ctx, (size_t)fi.total);
+		ctx->last_devices = 1;
+		if (lanes > 1 && fi.nsb >= (uint64_t)(2 * lanes)) {
+			ctx->last_devices = lanes;
+			return decompress_lanes(ctx, in, bytesoftype, fi, index, out, lanes);
+		}
+	}
+	if (!host_codes) {
+		void* a_src = device_alias(src, size);
+		void* a_dst = device_alias(dst, (size_t)fi.total);
+		if (a_src || a_dst) {
+			if ((!a_src && !ctx->in.ensure(size + 64)) || (!a_dst && !ctx->out.ensure((size_t)fi.total + 64)) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
+				return STENOS_ERROR_ALLOC;
+			if ((!a_src && hipMemcpy(ctx->in.p, src, size, hipMemcpyHostToDevice) != hipSuccess) ||
+			    hipMemcpy(ctx->sboff.p, index.data(), (fi.nsb + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			const size_t r = decompress_device(ctx, a_src ? a_src : ctx->in.p, bytesoftype, size, a_dst ? a_dst : ctx->out.p, (size_t)fi.total, ctx->sboff.as<uint64_t>(),
+							   index.data(), in, nullptr, true);
+			if (is_err(r))
+				return r;
+			if (!a_dst && hipMemcpy(dst, ctx->out.p, (size_t)fi.total, hipMemcpyDeviceToHost) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			return (size_t)fi.total;
+		}
+	}
+	if (fi.total >= kHostChunkedFrom && !host_codes) {
+		bool no_thread = false;
+		const size_t r = decompress_chunked(ctx, in, bytesoftype, fi, index, out, 0, fi.nsb, &no_thread);
+		if (!no_thread)
+			return r;
+	}
 	if (!ctx->in.ensure(size + 64) || !ctx->out.ensure((size_t)fi.total + 64) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
 		return STENOS_ERROR_ALLOC;
 	if (hipMemcpy(ctx->in.p, src, size, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1629,6 +1952,7 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 static stenos_context_s& one_shot_context()
 {
 	static thread_local stenos_context_s ctx;
+	ctx.threads = 1; // every parameter as a fresh context has it (the level is set by the caller)
 	ctx.max_nanoseconds = 0;
 	ctx.custom_shift = STENOS_NO_BLOCK_SHIFT;
 	return ctx;
@@ -1851,6 +2175,7 @@ size_t stenos_private_create_compression_header(size_t decompressed_size, size_t
 // device-pointer entry points (include/stenos_hip.h)
 // =====================================================================================================
 
+int stenos_hip_last_devices(stenos_context* ctx) { return ctx ? ctx->last_devices : 0; }
 int stenos_hip_device_count(void)
 {
 	int n = 0;

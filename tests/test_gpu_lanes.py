@@ -1,0 +1,81 @@
+"""Host-pointer calls on several devices (capi.cpp, compress_lanes / decompress_lanes): stenos_set_threads(ctx, n) lets a
+call use up to n devices, each taking a contiguous range of superblocks through a child context on a host thread of its
+own (reference dispatcher: stenos.cpp:909-1010, 1151-1202).  The test box has ONE GPU, so the lanes share it
+(STENOS_HIP_LANES_ON_ONE_DEVICE=1): what is checked is the orchestration -- the frame must be byte-identical to the
+single-device frame (roomy and tight destinations), and both decode paths must give the input back."""
+import os
+
+os.environ["STENOS_HIP_LANES_ON_ONE_DEVICE"] = "1"  # read once, at the first call with more than one thread
+
+import numpy as np
+import pytest
+
+from _libs import has_error, np_ptr
+from stenos_amd.datagen import generate
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from stenos_amd.api import load_library
+
+    return load_library()
+
+
+def _compress(lib, data, T, threads, dst_size=None, level=1, expect_lanes=None):
+    c = lib.stenos_make_context()
+    lib.stenos_set_level(c, level)
+    lib.stenos_set_threads(c, threads)
+    cap = lib.stenos_bound(data.nbytes) if dst_size is None else dst_size
+    out = np.full(cap + 64, 0x5A, dtype=np.uint8)
+    r = lib.stenos_compress_generic(c, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
+    used = lib.stenos_hip_last_devices(c)
+    lib.stenos_destroy_context(c)
+    if expect_lanes is not None:
+        assert used == expect_lanes, (used, expect_lanes)
+    assert (out[cap:] == 0x5A).all(), "wrote past dst_size"
+    return r, (None if has_error(r) else out[:r].copy())
+
+
+@pytest.mark.parametrize("kind,T,mib", [("rand12", 4, 160), ("walk", 2, 130), ("sine", 8, 129), ("rand", 4, 97), ("mixed", 3, 70)])
+@pytest.mark.parametrize("threads", [2, 3, 5])
+def test_lanes_frame_equals_single_device_frame(lib, kind, T, mib, threads):
+    n = (mib << 20) // T + 1234  # a partial block at the end, and not a multiple of the superblock
+    data = generate(kind, T, n, 11)
+    r1, f1 = _compress(lib, data, T, 1)
+    rn, fn = _compress(lib, data, T, threads, expect_lanes=threads)
+    assert not has_error(r1) and rn == r1
+    assert np.array_equal(fn, f1)
+    # decode on lanes and on one device
+    for th in (threads, 1):
+        c = lib.stenos_make_context()
+        lib.stenos_set_threads(c, th)
+        back = np.full(data.nbytes + 64, 0x5A, dtype=np.uint8)
+        assert lib.stenos_decompress_generic(c, np_ptr(fn), T, rn, np_ptr(back), data.nbytes) == data.nbytes
+        assert lib.stenos_hip_last_devices(c) == th
+        lib.stenos_destroy_context(c)
+        assert np.array_equal(back[: data.nbytes], data.view(np.uint8).ravel())
+        assert (back[data.nbytes:] == 0x5A).all()
+
+
+def test_lanes_with_tight_destinations(lib):
+    """dst_size at, slightly below and far below the frame size: the same result (frame or error) as on one device."""
+    T = 4
+    data = generate("rand12", T, (96 << 20) // T + 77, 5)
+    r1, f1 = _compress(lib, data, T, 1)
+    for cap in (r1 + 100000, r1 + 5, r1, r1 - 1, r1 - 70000, r1 // 2):
+        ra, fa = _compress(lib, data, T, 1, dst_size=cap)
+        rb, fb = _compress(lib, data, T, 3, dst_size=cap)
+        assert has_error(ra) == has_error(rb), (cap, hex(ra), hex(rb))
+        if not has_error(ra):
+            assert ra == rb and np.array_equal(fa, fb), cap
+
+
+def test_lanes_incompressible_input_at_the_bound(lib):
+    """Every superblock a copy, dst_size == stenos_bound: the frame fills the bound but for a few bytes."""
+    T = 4
+    data = generate("rand", T, (80 << 20) // T, 9)
+    r1, f1 = _compress(lib, data, T, 1)
+    r3, f3 = _compress(lib, data, T, 3, expect_lanes=3)
+    assert not has_error(r1) and r1 == r3 and np.array_equal(f1, f3)
