@@ -46,31 +46,47 @@ def parse():
     p.add_argument("--kind", default=None, help="another datagen kind for the chosen element size (experiments)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-full-entropy", action="store_true", help="skip the extra full-entropy (all COPY) measurement")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the int16 / double / level 2 / level 3 entries")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
     return p.parse_args()
 
 
-def cpu_baseline(sample, T, sample_desc):
+def cpu_share():
+    """CPUs granted by the container's cgroup quota (cpu.max), or None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(float(q) / float(p) + 0.5))
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return max(1, int(q / p + 0.5)) if q > 0 else None
+        except Exception:
+            return None
+
+
+def cpu_baseline(sample, T, sample_desc, level=1, reps=5):
     """The reference's own CPU path (oracle/_ref, unmodified sources, AVX2/BMI2 build) timed on this
-    host's cores on a bounded prefix of the same workload; falls back to the scalar C oracle ("port")."""
+    host's cores on a bounded prefix of the same workload, at the same level; falls back to the scalar C oracle ("port")."""
     import numpy as np
 
     from _libs import load_oracle, load_ref, np_ptr
 
     cores = os.cpu_count() or 1
+    share = cpu_share()  # CPUs a container's quota really grants (None: no quota)
     ref = load_ref(det=False)
     nb = sample.nbytes
     if ref is not None:
         out = np.zeros(ref.stenos_bound(nb), dtype=np.uint8)
         back = np.zeros(nb, dtype=np.uint8)
         res = {}
-        for threads in (1, cores):
+        for threads in sorted({1, cores} | ({min(cores, share + share // 2)} if share else set())):
             ctx = ref.stenos_make_context()
-            ref.stenos_set_level(ctx, 1)
+            ref.stenos_set_level(ctx, level)
             ref.stenos_set_threads(ctx, threads)
             best_e = best_d = 1e30
             r = 0
-            for _ in range(5):  # best of 5, as benchs/bench_to_csv.cpp:113-126
+            for _ in range(reps if threads > 1 else max(1, reps // 2)):  # best of 5, as benchs/bench_to_csv.cpp:113-126
                 t = time.perf_counter()
                 r = ref.stenos_compress_generic(ctx, np_ptr(sample), T, nb, np_ptr(out), out.nbytes)
                 best_e = min(best_e, time.perf_counter() - t)
@@ -83,14 +99,15 @@ def cpu_baseline(sample, T, sample_desc):
         use = max(res, key=lambda k: res[k][0])
         return {"value": round(res[use][0], 3), "unit": "GB/s", "cores": use, "kind": "reference", "sample": sample_desc,
                 "encode_gbps": round(res[use][1], 3), "decode_gbps": round(res[use][2], 3), "ratio": round(res[use][3], 4),
-                "single_thread_value": round(res[1][0], 3), "host_cores": cores}
+                "single_thread_value": round(res[1][0], 3), "host_cores": cores, "cpu_quota": share,
+                "threads_tried": {str(k): round(v[0], 3) for k, v in res.items()}}
     lib = load_oracle()
     small = sample[: 64 << 20]
     nb = small.nbytes
     out = np.zeros(lib.so_bound(nb), dtype=np.uint8)
     back = np.zeros(nb, dtype=np.uint8)
     t = time.perf_counter()
-    r = lib.so_compress(np_ptr(small), T, nb, np_ptr(out), out.nbytes, 1)
+    r = lib.so_compress(np_ptr(small), T, nb, np_ptr(out), out.nbytes, level)
     te = time.perf_counter() - t
     t = time.perf_counter()
     lib.so_decompress(np_ptr(out), T, r, np_ptr(back), nb, 1)
@@ -99,20 +116,31 @@ def cpu_baseline(sample, T, sample_desc):
             "encode_gbps": round(nb / te / 1e9, 3), "decode_gbps": round(nb / td / 1e9, 3), "ratio": round(nb / r, 4)}
 
 
-def run_workload(st, torch, src, T, steps, warmup, dist, world):
+def run_workload(st, torch, src, T, steps, warmup, dist, world, blocking=False):
     """Returns wall seconds for `steps` round trips (max over ranks), per-direction seconds, kernel ms, csize."""
     nbytes = src.numel()
     dst = torch.empty(st.bound(nbytes), dtype=torch.uint8, device=src.device)
     back = torch.empty_like(src)
     csize = 0
 
+    def enc():
+        if blocking:  # levels >= 2: the host finishes the frame (zstd) inside the call
+            return st.compress(src, T, dst)
+        st.compress(src, T, dst, wait=False)
+        return st.finish()  # the frame size is a host value the decoder needs
+
+    def dec(csize):
+        idx, nsb = st.last_index()
+        if blocking:
+            st.decompress(dst, T, csize, back, index_ptr=idx if nsb else None)
+        else:
+            st.decompress(dst, T, csize, back, index_ptr=idx if nsb else None, wait=False)
+            st.finish()
+
     def step():
         nonlocal csize
-        st.compress(src, T, dst, wait=False)
-        csize = st.finish()  # the frame size is a host value the decoder needs
-        idx, _ = st.last_index()
-        st.decompress(dst, T, csize, back, index_ptr=idx, wait=False)
-        st.finish()
+        csize = enc()
+        dec(csize)
 
     for _ in range(warmup):
         step()
@@ -125,12 +153,9 @@ def run_workload(st, torch, src, T, steps, warmup, dist, world):
     t0 = time.perf_counter()
     for _ in range(steps):
         ev[0].record()
-        st.compress(src, T, dst, wait=False)
-        csize = st.finish()
+        csize = enc()
         ev[1].record()
-        idx, _ = st.last_index()
-        st.decompress(dst, T, csize, back, index_ptr=idx, wait=False)
-        st.finish()
+        dec(csize)
         ev[2].record()
         ev[2].synchronize()
         enc_s += ev[0].elapsed_time(ev[1]) / 1e3
@@ -155,6 +180,53 @@ CONFIGS = {
     "int16": ("walk", 2, "configs[3] shard: {gib:g} GiB int16 random walk per GPU (x += u % 17 - 8, splitmix64 seed 7 + rank), bytesof=2, level 1"),
     "double": ("sine", 8, "configs[2] at level 1: {gib:g} GiB double sin(i * 0.001) per GPU, bytesof=8"),
 }
+
+
+# The other BASELINE.json configurations, one bench entry each under "other_configs" at N=1 (the driver times them with the
+# headline): name -> (datagen kind, bytesoftype, level, GiB, steps, MiB of the CPU sample, description)
+OTHER_CONFIGS = {
+    "int16_walk_level1": ("walk", 2, 1, 8.0, 3, 512, "configs[3], one shard: 8 GiB int16 random walk (x += u % 17 - 8, splitmix64 seed 7), bytesof=2, level 1"),
+    "double_sine_level1": ("sine", 8, 1, 8.0, 3, 512, "configs[2] at level 1: 8 GiB double sin(i * 0.001), bytesof=8 (the level-2 frame is the same stream)"),
+    "double_sine_level2": ("sine", 8, 2, 2.0, 2, 256, "configs[2]: double sin(i * 0.001), bytesof=8, level 2 (block codec on the GPU, LZ4-dry estimate and zstd attempts on the host), 2 GiB"),
+    "bytes_smooth_level3": ("smooth8", 1, 3, 2.0, 2, 256, "configs[4]: bytes, bytesof=1, level 3 (256 KiB superblocks; block stream + zstd, code 5), smooth signal 128 + 100 sin(0.01 i) +- 2, 2 GiB"),
+}
+
+
+def measure_other(name, torch, dist, dev, with_cpu):
+    import numpy as np
+
+    from stenos_amd.api import Stenos
+    from stenos_amd.datagen import generate, generate_torch
+
+    kind, T, level, gib, steps, cpu_mib, desc = OTHER_CONFIGS[name]
+    n = int(gib * (1 << 30)) // T
+    if kind == "smooth8":
+        src = torch.from_numpy(generate(kind, T, n, 9)).to(dev)
+    else:
+        src = generate_torch(kind, T, n, seed=7 if kind == "walk" else 42, device=dev)
+    st = Stenos(level=level)
+    st.set_profiling(True)
+    r = run_workload(st, torch, src, T, steps, 1, dist, 1, blocking=level >= 2 or T == 1)
+    assert r["ok"], name
+    nb = src.numel()
+    e = {"workload": desc, "bytesoftype": T, "level": level, "value": round(nb * steps / r["wall"] / 1e9, 3), "unit": "GB/s", "steps": steps,
+         "compression_ratio": round(nb / r["csize"], 4), "encode_gbps": round(nb * steps / r["enc_s"] / 1e9, 3), "decode_gbps": round(nb * steps / r["dec_s"] / 1e9, 3)}
+    if level == 1 and T > 1:
+        algo = nb + r["csize"]
+        roof = roofline("encode_superblocks", algo, r["kenc_ms"])
+        roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"]).items() if k in ("achieved", "frac", "kernel_ms")}
+        e["roofline"] = roof
+    else:
+        e["roofline"] = None
+        e["note"] = "host-bound: one LZ4-dry estimate and up to two zstd calls per superblock run on the host's cores between the GPU passes"
+    if with_cpu:
+        nbytes = min((cpu_mib << 20) + 4000 * T, nb)
+        sample = src[:nbytes].cpu().numpy()
+        e["cpu_baseline"] = cpu_baseline(sample, T, f"first {cpu_mib} MiB + {4000 * T} B of the same workload, same level, best of 3", level=level, reps=3)
+    st.close()
+    del src
+    torch.cuda.empty_cache()
+    return e
 
 
 def roofline(kernel, algo_bytes, kernel_ms, traffic=None, traffic_source=None):
@@ -334,48 +406,75 @@ def main():
         out["parity_prefix_bytes"] = reference_prefix_parity(st, torch, src, T, mib << 20)
         out["host_pointer"] = host_pointer_rate(T, sample)
         del sample
+    if world == 1 and args.config == "int32" and not args.kind and not args.no_other_configs:
+        del src
+        torch.cuda.empty_cache()
+        out["other_configs"] = {name: measure_other(name, torch, dist, dev, not args.no_cpu_baseline) for name in OTHER_CONFIGS}
+        src = None
     if world > 1:
         # The one exchange of the sharded form, after the timed region and timed on its own: the compressed segments go to
         # rank 0 (RCCL over xGMI with the nccl backend), rank 0 cuts the assembled frame again and every rank decodes its
         # segment; each rank checks its slice against its input.
         from stenos_amd.sharded import decompress_sharded, gather_frames
 
+        # Every stage that can fail on one rank alone (allocation, a codec call) is followed by an all_reduce of an ok flag:
+        # either all ranks enter the next collective or none does, so a local failure is reported instead of hanging the job.
         extra = {}
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+
+        def all_ok(ok):
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() == 1.0)
+
+        stage, err = "compress", None
+        csize, frame, index, back = 0, None, None, None
         try:
             dst = torch.empty(st.bound(nbytes), dtype=torch.uint8, device=dev)
             csize = st.compress(src, T, dst)
             local = dst[:csize]
+            back = torch.empty_like(src)
+        except Exception as e:
+            err = repr(e)[:300]
+        if all_ok(err is None):
+            stage = "gather"
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            frame = gather_frames(local, world * nbytes)
+            frame = gather_frames(local, world * nbytes)  # (collectives only: a failure here is a failure of the job)
             torch.cuda.synchronize()
             dist.barrier()
             gather_s = time.perf_counter() - t0
-            sizes = torch.tensor([float(csize)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            sizes = torch.tensor([float(csize)], dtype=torch.float64, device=cdev)
             dist.all_reduce(sizes)
             moved = float(sizes.item()) - csize if rank == 0 else 0.0
-            index = st.frame_index(frame, T, frame.numel()) if rank == 0 else None
-            back = torch.empty_like(src)
+            try:
+                index = st.frame_index(frame, T, frame.numel()) if rank == 0 else None
+            except Exception as e:
+                err = repr(e)[:300]
+            if all_ok(err is None):
+                stage = "scatter_decode"
+                derr = []
 
-            def decode(seg, nb):
-                st.decompress(seg, T, seg.numel(), back[:nb])
-                return back[:nb]
+                def decode(seg, nb):
+                    try:
+                        st.decompress(seg, T, seg.numel(), back[:nb])
+                    except Exception as e:  # reported after the collectives of decompress_sharded are through
+                        derr.append(repr(e)[:300])
+                    return back[:nb]
 
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            part, o0, o1 = decompress_sharded(decode, frame, index, world * nbytes, T, dev)
-            torch.cuda.synchronize()
-            dist.barrier()
-            scatter_decode_s = time.perf_counter() - t0
-            ok = torch.tensor([1.0 if (o1 - o0 == nbytes and o0 == rank * nbytes and torch.equal(part, src)) else 0.0], dtype=torch.float64,
-                              device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            extra = {"gather_ms": round(gather_s * 1e3, 3), "gather_bytes_to_rank0": int(moved), "gather_gbps": round(moved / gather_s / 1e9, 2) if gather_s > 0 else None,
-                     "scatter_decode_ms": round(scatter_decode_s * 1e3, 3), "sharded_roundtrip_ok": bool(ok.item() == 1.0), "backend": dist.get_backend()}
-        except Exception as e:  # the headline line must not be lost to the exchange
-            extra = {"gather_error": repr(e)[:300]}
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                part, o0, o1 = decompress_sharded(decode, frame, index, world * nbytes, T, dev)
+                torch.cuda.synchronize()
+                dist.barrier()
+                scatter_decode_s = time.perf_counter() - t0
+                good = not derr and o1 - o0 == nbytes and o0 == rank * nbytes and bool(torch.equal(part, src))
+                extra = {"gather_ms": round(gather_s * 1e3, 3), "gather_bytes_to_rank0": int(moved), "gather_gbps": round(moved / gather_s / 1e9, 2) if gather_s > 0 else None,
+                         "scatter_decode_ms": round(scatter_decode_s * 1e3, 3), "sharded_roundtrip_ok": all_ok(good), "backend": dist.get_backend()}
+        if not extra:
+            extra = {"gather_error": f"stage {stage}: " + (err or "another rank failed")}
         if rank == 0:
             out["sharded_exchange"] = extra
     if rank == 0:

@@ -11,6 +11,7 @@
 // STENOS_ERROR_INVALID_INSTRUCTION_SET (the reference's code for "required instruction set missing").
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -40,9 +41,36 @@ typedef size_t (*zstd_compress_fn)(void*, size_t, const void*, size_t, int);
 typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
 typedef unsigned (*zstd_iserror_fn)(size_t);
 typedef int (*zstd_maxclevel_fn)(void);
+typedef void* (*zstd_createcctx_fn)(void);
+typedef size_t (*zstd_freecctx_fn)(void*);
+typedef size_t (*zstd_compresscctx_fn)(void*, void*, size_t, const void*, size_t, int);
 struct Zstd {
 	zstd_maxclevel_fn max_level = nullptr;
-	zstd_compress_fn compress = nullptr;
+	zstd_compress_fn compress_once = nullptr;
+	zstd_createcctx_fn create_cctx = nullptr;
+	zstd_freecctx_fn free_cctx = nullptr;
+	zstd_compresscctx_fn compress_cctx = nullptr;
+	// ZSTD_compress allocates and frees a context of several hundred KB per call, which serialises dozens of worker
+	// threads in the allocator; each thread keeps one context instead (ZSTD_compressCCtx, what the reference calls,
+	// zstd_wrapper.h:81-83: same bytes)
+	size_t compress(void* dst, size_t cap, const void* src, size_t n, int level) const
+	{
+		struct Holder {
+			void* c = nullptr;
+			zstd_freecctx_fn fr = nullptr;
+			~Holder()
+			{
+				if (c && fr)
+					fr(c);
+			}
+		};
+		static thread_local Holder h;
+		if (!h.c && create_cctx) {
+			h.c = create_cctx();
+			h.fr = free_cctx;
+		}
+		return h.c ? compress_cctx(h.c, dst, cap, src, n, level) : compress_once(dst, cap, src, n, level);
+	}
 	zstd_decompress_fn decompress = nullptr;
 	zstd_iserror_fn is_error = nullptr;
 	bool ok = false;
@@ -54,11 +82,16 @@ struct Zstd {
 			h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
 		if (!h)
 			return;
-		compress = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
+		compress_once = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
+		create_cctx = (zstd_createcctx_fn)dlsym(h, "ZSTD_createCCtx");
+		free_cctx = (zstd_freecctx_fn)dlsym(h, "ZSTD_freeCCtx");
+		compress_cctx = (zstd_compresscctx_fn)dlsym(h, "ZSTD_compressCCtx");
+		if (!create_cctx || !free_cctx || !compress_cctx)
+			create_cctx = nullptr;
 		decompress = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
 		is_error = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
 		max_level = (zstd_maxclevel_fn)dlsym(h, "ZSTD_maxCLevel");
-		ok = compress && decompress && is_error && max_level;
+		ok = compress_once && decompress && is_error && max_level;
 	}
 };
 Zstd& zstd()
@@ -549,14 +582,45 @@ size_t host_copy_superblock(const uint8_t* src, size_t bytes, uint8_t* dst, size
 }
 
 // Host side worker threads for the zstd stages of levels >= 2 (one superblock per task).
+#ifndef STENOS_HOST_THREADS_CAP
+#define STENOS_HOST_THREADS_CAP 64
+#endif
+constexpr unsigned HOST_THREADS_DEFAULT_CAP = STENOS_HOST_THREADS_CAP; // workers of the strategy layer unless STENOS_HOST_THREADS says otherwise (at most 256)
 unsigned host_threads()
 {
 	static const unsigned threads = [] { // (read once: no environment look-ups on the call path)
 		unsigned n = std::thread::hardware_concurrency();
+		// a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) is what the workers really get: beyond about 1.5 x
+		// of it more threads only take time slices from each other (measured on a 16-CPU share of a 256-thread host:
+		// 24 workers 13.8 GB/s, 64: 11.5, 256: 4.7 for doubles at level 2)
+		{
+			double quota = 0, period = 0;
+			if (FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+				char q[32] = { 0 };
+				if (fscanf(fp, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0)
+					quota = atof(q);
+				fclose(fp);
+			}
+			else if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+				if (fscanf(fq, "%lf", &quota) != 1)
+					quota = 0;
+				fclose(fq);
+				if (FILE* fr = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+					if (fscanf(fr, "%lf", &period) != 1)
+						period = 0;
+					fclose(fr);
+				}
+			}
+			if (quota > 0 && period > 0) {
+				const unsigned share = (unsigned)(quota / period * 1.5 + 0.5);
+				n = share < n ? (share < 1 ? 1u : share) : n;
+			}
+		}
+		n = n > HOST_THREADS_DEFAULT_CAP ? HOST_THREADS_DEFAULT_CAP : n;
 		if (const char* e = getenv("STENOS_HOST_THREADS"))
 			if (atoi(e) > 0)
 				n = (unsigned)atoi(e);
-		return n > 64 ? 64u : n < 1 ? 1u : n;
+		return n > 256 ? 256u : n < 1 ? 1u : n;
 	}();
 	return threads;
 }
@@ -701,26 +765,37 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	j.fixed_capacity = 1;
 	j.qprod = ctx->qprod.as<uint32_t>();
 	uint64_t* d_carry = (uint64_t*)(misc + 24);
-	if (stenos_k_launch_init(misc, 0, nullptr, 0, nullptr, 0, stream) != hipSuccess || stenos_k_launch_encode(j, 0, nblocks, stream) != hipSuccess || stenos_k_launch_plan(j, 0, f.nsb, stream) != hipSuccess ||
-	    stenos_k_launch_scan(j, 0, f.nsb, d_carry, stream) != hipSuccess || stenos_k_launch_pack(j, 0, f.nsb, stream) != hipSuccess)
+	// The block codec's verdict per superblock first (sizes only: nothing is packed or moved yet) ...
+	if (stenos_k_launch_init(misc, 0, nullptr, 0, nullptr, 0, stream) != hipSuccess || stenos_k_launch_encode(j, 0, nblocks, stream) != hipSuccess || stenos_k_launch_plan(j, 0, f.nsb, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	std::vector<uint8_t> code(f.nsb);
 	std::vector<uint32_t> csize(f.nsb), qprod(f.nsb);
 	std::vector<uint64_t> sboff(f.nsb + 1);
 	if (hipMemcpyAsync(code.data(), j.sb_code, f.nsb, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 	    hipMemcpyAsync(csize.data(), j.sb_csize, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-	    hipMemcpyAsync(qprod.data(), j.qprod, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-	    hipMemcpyAsync(sboff.data(), j.sb_off, (f.nsb + 1) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-	    hipStreamSynchronize(stream) != hipSuccess)
+	    hipMemcpyAsync(qprod.data(), j.qprod, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
 	PhaseTrace trace;
-	HostBuf& blocks = ctx->h_blocks;
-	const size_t blocks_size = (size_t)sboff[f.nsb];
-	if (!blocks.ensure(blocks_size + 64))
-		return STENOS_ERROR_ALLOC;
-	if (blocks_size && hipMemcpy(blocks.data(), j.dst, blocks_size, hipMemcpyDeviceToHost) != hipSuccess)
+	// ... and, for an input that lives on the device (h_src == NULL), the part of it the estimator looks at: the first
+	// 1/16 of every superblock (stenos.cpp:497-499), one strided copy into a host image of the input.  The rest of a
+	// superblock is fetched only if it ends up going through zstd as it is (or as a copy).
+	const bool lazy_src = h_src == nullptr;
+	if (lazy_src) {
+		if (!ctx->h_in.ensure(bytes + 64))
+			return STENOS_ERROR_ALLOC;
+		uint8_t* img = ctx->h_in.data();
+		const uint64_t whole = bytes / f.sb;
+		if (whole && f.sb / 16 &&
+		    hipMemcpy2DAsync(img, f.sb, d_src, f.sb, f.sb / 16, (size_t)whole, hipMemcpyDeviceToHost, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		if (bytes > whole * f.sb && hipMemcpyAsync(img + whole * f.sb, d_src + whole * f.sb, bytes - whole * f.sb, hipMemcpyDeviceToHost, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED; // (the last, partial superblock: all of it)
+		h_src = img;
+	}
+	if (hipStreamSynchronize(stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	trace.mark("block streams to host");
+	trace.mark("verdicts and samples to host");
+	HostBuf& blocks = ctx->h_blocks;
 	// transposed views for the estimator and the transposed zstd strategies (levels > 2 only, stenos.cpp:515-537)
 	const bool transposed = T > 1 && level > 2;
 	HostBuf &shuf = ctx->h_shuf, &mid0 = ctx->h_mid0, &mid1 = ctx->h_mid1;
@@ -830,6 +905,53 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		return r + 4;
 	};
 
+	// What every superblock becomes, then only the block streams that are kept are packed and brought to the host: the
+	// reference abandons the block codec for a superblock after 1/16 of it when the ratio target fails
+	// (block_compress.h:1266-1274) -- here the verdict comes from the sizes, and an abandoned superblock costs neither a
+	// pack nor a transfer.
+	std::vector<int> all_choice(f.nsb);
+	parallel_for(f.nsb, [&](uint64_t s) { all_choice[s] = decide(s); });
+	trace.mark("estimates");
+	{
+		std::vector<uint8_t> keep(f.nsb);
+		uint64_t dropped = 0;
+		for (uint64_t s = 0; s < f.nsb; ++s) {
+			keep[s] = all_choice[s] == 1;
+			dropped += code[s] == 1 && !keep[s];
+		}
+		if (dropped) {
+			if (!ctx->tmp2.ensure(f.nsb + 64) || hipMemcpyAsync(ctx->tmp2.p, keep.data(), f.nsb, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			    stenos_k_launch_keep_superblocks(ctx->tmp2.as<uint8_t>(), j.sb_code, j.sb_csize, f.nsb, stream) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+		}
+		if (stenos_k_launch_scan(j, 0, f.nsb, d_carry, stream) != hipSuccess || stenos_k_launch_pack(j, 0, f.nsb, stream) != hipSuccess ||
+		    hipMemcpyAsync(sboff.data(), j.sb_off, (f.nsb + 1) * 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		const size_t blocks_size = (size_t)sboff[f.nsb];
+		if (!blocks.ensure(blocks_size + 64))
+			return STENOS_ERROR_ALLOC;
+		if (blocks_size && hipMemcpyAsync(blocks.data(), j.dst, blocks_size, hipMemcpyDeviceToHost, stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		if (lazy_src) { // raw bytes of the superblocks that go through zstd as they are (runs of neighbours in one copy)
+			uint8_t* img = ctx->h_in.data();
+			for (uint64_t s = 0; s < f.nsb;) {
+				if (all_choice[s] == 1) {
+					++s;
+					continue;
+				}
+				uint64_t e = s;
+				while (e < f.nsb && all_choice[e] != 1)
+					++e;
+				const size_t b0 = (size_t)(s * f.sb), b1 = (size_t)(e * f.sb < bytes ? e * f.sb : bytes);
+				if (hipMemcpyAsync(img + b0, d_src + b0, b1 - b0, hipMemcpyDeviceToHost, stream) != hipSuccess)
+					return STENOS_ERROR_UNDEFINED;
+				s = e;
+			}
+		}
+		if (hipStreamSynchronize(stream) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		trace.mark("block streams to host");
+	}
 	// zstd's result depends on the capacity only below ZSTD_compressBound of its input, so the superblocks of a
 	// batch are compressed in parallel into roomy scratch buffers and then laid out in order; a superblock that
 	// meets less room than that in the caller's buffer (the end of a tight buffer) is redone with the exact
@@ -838,9 +960,9 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	uint64_t batch = ((size_t)256 << 20) / f.sb;
 	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
 	std::vector<int> choice;
-	std::unique_ptr<uint8_t[]> scratch(new (std::nothrow) uint8_t[(size_t)(batch < f.nsb ? batch : f.nsb) * ample]);
-	if (!scratch)
+	if (!ctx->h_stage.ensure((size_t)(batch < f.nsb ? batch : f.nsb) * ample)) // (kept by the context: a fresh 100 MB allocation per call costs more than the zstd calls)
 		return STENOS_ERROR_ALLOC;
+	struct { uint8_t* p; uint8_t* get() const { return p; } } scratch = { ctx->h_stage.data() };
 	std::vector<size_t> sizes;
 	std::vector<uint64_t> dslot; // position of a choice-4 superblock in the batch's delta buffer
 	std::vector<size_t> offsets;
@@ -848,9 +970,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	size_t off = f.header;
 	for (uint64_t s0 = 0; s0 < f.nsb; s0 += batch) {
 		const uint64_t cnt = (s0 + batch < f.nsb ? s0 + batch : f.nsb) - s0;
-		choice.assign(cnt, 0);
-		parallel_for(cnt, [&](uint64_t k) { choice[k] = decide(s0 + k); });
-		trace.mark("estimates");
+		choice.assign(all_choice.begin() + (ptrdiff_t)s0, all_choice.begin() + (ptrdiff_t)(s0 + cnt));
 #ifdef STENOS_HOST_TRACE
 		{
 			unsigned h[5] = { 0, 0, 0, 0, 0 };
@@ -946,12 +1066,11 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 		// the strategy layer needs the input on the host (estimator, zstd): fetch it, assemble the frame there
 		const size_t roomy = f.header + f.nsb * 4 + bytes + f.sb / 128 + 4096; // beyond the largest frame (all copies) + ZSTD_compressBound's margin the capacity no longer matters
 		const size_t cap = dst_size < roomy ? dst_size : roomy;
-		HostBuf &h_src = ctx->h_in, &h_out = ctx->h_out;
-		if (!h_src.ensure(bytes + 64) || !h_out.ensure(cap + 64))
+		HostBuf& h_out = ctx->h_out;
+		if (!h_out.ensure(cap + 64))
 			return STENOS_ERROR_ALLOC;
-		if (hipMemcpyAsync(h_src.data(), d_src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		size_t r = compress_strategy(ctx, h_src.data(), (const uint8_t*)d_src, T, bytes, h_out.data(), cap, level, f, stream);
+		// (no host copy of the input: the strategy layer fetches what it looks at)
+		size_t r = compress_strategy(ctx, nullptr, (const uint8_t*)d_src, T, bytes, h_out.data(), cap, level, f, stream);
 		if (is_err(r))
 			return r;
 		if (hipMemcpyAsync(d_dst, h_out.data(), r, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)

@@ -36,6 +36,7 @@ hipError_t stenos_k_launch_encode(const codec::FrameJob& j, uint64_t b_begin, ui
 hipError_t stenos_k_launch_plan(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
 hipError_t stenos_k_launch_scan(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, uint64_t* carry, hipStream_t stream);
 hipError_t stenos_k_launch_resolve(const codec::FrameJob& j, hipStream_t stream);
+hipError_t stenos_k_launch_keep_superblocks(const uint8_t* keep, uint8_t* code, uint32_t* csize, uint64_t nsb, hipStream_t stream);
 hipError_t stenos_k_launch_pack(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
 hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream);
 hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream);

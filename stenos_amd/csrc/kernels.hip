@@ -286,6 +286,17 @@ __global__ __launch_bounds__(1024) void scan_superblocks(const uint32_t* __restr
 	}
 }
 
+// levels >= 2: the host has decided which superblocks keep their block stream (keep[s] != 0); the others leave no
+// payload behind (code 0, size 0: pack_frame then writes their 4-byte header only)
+__global__ __launch_bounds__(256) void keep_superblocks(const uint8_t* __restrict__ keep, uint8_t* __restrict__ code, uint32_t* __restrict__ csize, uint64_t nsb)
+{
+	const uint64_t s = blockIdx.x * 256ull + threadIdx.x;
+	if (s < nsb && !keep[s]) {
+		code[s] = 0;
+		csize[s] = 0;
+	}
+}
+
 // One wavefront replays the capacity rules where the parallel plan could not clear them.
 __global__ __launch_bounds__(64) void resolve_frame(FrameJob j)
 {
@@ -488,6 +499,14 @@ hipError_t stenos_k_launch_scan(const FrameJob& j, uint64_t s_begin, uint64_t s_
 	if (s_end <= s_begin)
 		return hipSuccess;
 	hipLaunchKernelGGL(scan_superblocks, dim3(1), dim3(1024), 0, stream, j.sb_csize, s_begin, s_end - s_begin, carry, j.sb_off, j.total);
+	return hipGetLastError();
+}
+
+hipError_t stenos_k_launch_keep_superblocks(const uint8_t* keep, uint8_t* code, uint32_t* csize, uint64_t nsb, hipStream_t stream)
+{
+	if (nsb == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(keep_superblocks, dim3((uint32_t)((nsb + 255) / 256)), dim3(256), 0, stream, keep, code, csize, nsb);
 	return hipGetLastError();
 }
 

@@ -78,13 +78,20 @@ def gather_frames(local_frame: torch.Tensor, total_bytes: int, group=None) -> to
     return None
 
 
-def compress_sharded(compress: Callable[[torch.Tensor], torch.Tensor], data: torch.Tensor, bytesoftype: int, group=None):
-    """data: this rank's view of the WHOLE array (uint8).  Each rank compresses its own superblock range
-    with `compress` (returns the exact-length frame of a range) and rank 0 gets the assembled frame."""
+def compress_sharded(compress: Callable[[torch.Tensor], torch.Tensor], data: torch.Tensor, bytesoftype: int, group=None, total_bytes: int | None = None):
+    """Each rank compresses its own superblock range with `compress` (returns the exact-length frame of a range) and
+    rank 0 gets the assembled frame.  data (uint8): with total_bytes given, ONLY this rank's range of the array -- bytes
+    shard_ranges(total_bytes, ...)[rank], which is what a rank of a large job holds; without it, the whole array."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    begin, end = shard_ranges(data.numel(), bytesoftype, world)[rank]
-    frame = compress(data[begin:end].contiguous())
-    return gather_frames(frame, data.numel(), group)
+    if total_bytes is None:
+        total_bytes = data.numel()
+        begin, end = shard_ranges(total_bytes, bytesoftype, world)[rank]
+        data = data[begin:end]
+    else:
+        begin, end = shard_ranges(total_bytes, bytesoftype, world)[rank]
+        assert data.numel() == end - begin, "this rank's slice must be its shard_ranges() range"
+    frame = compress(data.contiguous())
+    return gather_frames(frame, total_bytes, group)
 
 
 def _wire(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -42,9 +42,14 @@ WORKER = textwrap.dedent("""
         assert r < (1 << 63)
         return torch.from_numpy(out[:r].copy())
     frame = compress_sharded(compress, torch.from_numpy(data), T)
+    # ... and with every rank holding only its own range, as the ranks of a large job do
+    from stenos_amd.sharded import shard_ranges
+    b, e = shard_ranges(data.nbytes, T, dist.get_world_size())[dist.get_rank()]
+    frame2 = compress_sharded(compress, torch.from_numpy(data.view(np.uint8).ravel()[b:e].copy()), T, total_bytes=data.nbytes)
     if dist.get_rank() == 0:
         whole = compress(torch.from_numpy(data))
         assert torch.equal(frame, whole), "sharded frame differs from the single-process frame"
+        assert torch.equal(frame2, whole), "frame of per-rank slices differs from the single-process frame"
         back = np.zeros(data.nbytes, dtype=np.uint8)
         f = frame.numpy()
         assert lib.stenos_decompress(f.ctypes.data, T, f.nbytes, back.ctypes.data, back.nbytes) == data.nbytes
