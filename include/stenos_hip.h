@@ -18,11 +18,14 @@ extern "C" {
 STENOS_EXPORT int stenos_hip_device_count(void);
 
 /* Bytes of device workspace the two calls below need for `bytes` of input (scratch slots, size and
- * offset tables).  The context allocates and keeps it; this is for capacity planning. */
+ * offset tables) when the destination holds stenos_bound(bytes).  With a smaller destination every block goes through
+ * a scratch slot instead of the fused kernel's staging buffers and the figure is up to about 1.03 x bytes higher.
+ * The context allocates and keeps it; this is for capacity planning. */
 STENOS_EXPORT size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes);
 
 /* Compress `bytes` of device memory into a Stenos frame in device memory.  Uses ctx's level and
- * block-size settings.  Enqueues on `stream`, then waits for the 8-byte size to come back.
+ * block-size settings; a time limit (stenos_set_max_nanoseconds) is a feature of the host-pointer calls only:
+ * with one set these entry points return STENOS_ERROR_INVALID_PARAMETER.  Enqueues on `stream`, then waits for the 8-byte size to come back.
  * Returns the frame size or an error code (test with stenos_has_error). */
 STENOS_EXPORT size_t stenos_hip_compress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, void* stream);
 
@@ -64,6 +67,11 @@ STENOS_EXPORT size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t
  * device; frames are byte-identical to single-device frames.  The environment variable STENOS_HIP_DEVICES caps the
  * number.  This call returns how many devices the last host-pointer call on ctx used (1: the single-device path). */
 STENOS_EXPORT int stenos_hip_last_devices(stenos_context* ctx);
+
+/* The fused encoder's waits for frame offsets are bounded; a launch that gives up (never observed) is redone without that
+ * kernel instead of failing the call.  Returns how often that has happened on ctx.  inject > 0 (tests): the next
+ * `inject` fused launches are treated as if they had given up. */
+STENOS_EXPORT int stenos_hip_fused_fallbacks(stenos_context* ctx, int inject);
 
 /* Kernel timing for benchmarks: when enabled, HIP events are recorded on the job's stream around the
  * dominant kernel of each direction: which = 0, the encoder (encode_superblocks, the fused kernel; encode_blocks

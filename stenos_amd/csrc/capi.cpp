@@ -241,6 +241,13 @@ struct stenos_context_s {
 	bool ev_valid[2] = { false, false };
 	hipStream_t up_stream = nullptr, main_stream = nullptr; // chunked host-pointer calls: uploads / coding + downloads
 	int last_devices = 1; // devices the last host-pointer call used
+	// what the last compression was asked to do: a fused launch that gave up waiting is done again without the fused kernel
+	const void* job_src = nullptr;
+	void* job_dst = nullptr;
+	size_t job_T = 0, job_bytes = 0;
+	bool no_fused = false;
+	int fused_fallbacks = 0;      // times that happened (stenos_hip_fused_fallbacks)
+	int inject_chain_timeout = 0; // test hook: the next n fused launches are treated as if they had given up
 	int device = -1; // the device the buffers above live on (the one that was current when they were first needed)
 	// host-pointer calls with stenos_set_threads(ctx, n > 1): one child context per further device (or per stand-in lane),
 	// used from a host thread of its own (multi_device below)
@@ -462,7 +469,7 @@ size_t enqueue_compress(stenos_context_s* ctx, const uint8_t* d_src, size_t T, s
 	// Safe superblocks that consist of full blocks go through the fused kernel (encode + offsets + store in one launch).
 	// (offset 0 means "not published yet" to the fused kernel, so frames without a header stay on the other path)
 	uint64_t s_fused = 0;
-	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T))
+	if (level >= 1 && header > 0 && stenos_k_fused_supported((uint32_t)T) && !ctx->no_fused)
 		s_fused = f.nfull / f.bps < s_tight ? f.nfull / f.bps : s_tight;
 	// One arena serves both: the staging streams of the fused superblocks, then (the fused kernel is done by
 	// then) the 16-byte aligned slots of the remaining blocks, addressed by their absolute block number.
@@ -1104,6 +1111,10 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 	ctx->job_kind = 1;
 	ctx->job_stream = stream;
 	ctx->job_dst_size = dst_size;
+	ctx->job_src = d_src;
+	ctx->job_dst = d_dst;
+	ctx->job_T = T;
+	ctx->job_bytes = bytes;
 	return wait ? finish_job(ctx) : 0;
 }
 
@@ -2295,6 +2306,14 @@ size_t stenos_private_create_compression_header(size_t decompressed_size, size_t
 // =====================================================================================================
 
 int stenos_hip_last_devices(stenos_context* ctx) { return ctx ? ctx->last_devices : 0; }
+int stenos_hip_fused_fallbacks(stenos_context* ctx, int inject)
+{
+	if (!ctx)
+		return 0;
+	if (inject > 0)
+		ctx->inject_chain_timeout = inject;
+	return ctx->fused_fallbacks;
+}
 int stenos_hip_device_count(void)
 {
 	int n = 0;
@@ -2355,9 +2374,26 @@ size_t finish_job(stenos_context_s* ctx)
 	ctx->job_kind = 0;
 	if (kind == 1) {
 		const uint64_t total = ctx->h_total[0];
-		const uint32_t estatus = *(const uint32_t*)((const uint8_t*)ctx->h_total + 12);
-		if (estatus & codec::ENCODE_STATUS_CHAIN_TIMEOUT) // the fused path gave up waiting (never seen; reported rather than hung)
-			return STENOS_ERROR_UNDEFINED;
+		uint32_t estatus = *(const uint32_t*)((const uint8_t*)ctx->h_total + 12);
+		if (ctx->inject_chain_timeout > 0 && ctx->job_src && !ctx->no_fused) {
+			--ctx->inject_chain_timeout;
+			estatus |= codec::ENCODE_STATUS_CHAIN_TIMEOUT;
+		}
+		if (estatus & codec::ENCODE_STATUS_CHAIN_TIMEOUT) {
+			// The fused kernel gave up waiting for a frame offset (its waits are bounded so that a scheduling accident cannot
+			// hang the device; never seen in practice).  The frame is then produced once more by the kernels that need no
+			// such wait (encode_blocks / plan / scan / pack); only when that fails too is the call an error.
+			if (ctx->no_fused || !ctx->job_src)
+				return STENOS_ERROR_UNDEFINED;
+			ctx->no_fused = true;
+			++ctx->fused_fallbacks;
+			const void* src = ctx->job_src;
+			ctx->job_src = nullptr;
+			const size_t r = compress_device(ctx, src, ctx->job_T, ctx->job_bytes, ctx->job_dst, ctx->job_dst_size, ctx->job_stream, true);
+			ctx->no_fused = false;
+			return r;
+		}
+		ctx->job_src = nullptr;
 		return (estatus || total > ctx->job_dst_size) ? STENOS_ERROR_DST_OVERFLOW : (size_t)total;
 	}
 	const uint32_t status = *(const uint32_t*)((const uint8_t*)ctx->h_total + 32);

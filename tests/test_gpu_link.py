@@ -41,3 +41,22 @@ def test_the_references_own_round_trip_test_runs_against_this_library():
     assert "Test error" not in out, out[-800:]
     assert rc in (None, 0), (rc, out[-800:])
     assert out.count("done") > 20000, "the test did not get far enough: " + out[-500:]
+
+
+def test_the_references_cvector_test_links_and_runs_against_this_library():
+    """stenos/cvector.hpp (header only) drives stenos_private_compress_block / _decompress_block / _block_size ... one
+    superblock per call (cvector.hpp:1383-1416).  Its own test (tests/test_cvector.cpp:75-740), compiled where it lies and
+    linked with this library, must not fail a check; it takes far longer than a test slot here, because every access to
+    a compressed bucket is a device call of ~0.2 ms (not a use this path is for), so a bounded run that is
+    still going without a failed check is a pass."""
+    import tempfile
+
+    with tempfile.TemporaryFile() as log:
+        try:
+            rc = subprocess.run(["stdbuf", "-oL", "-eL", _binary("ref_test_cvector")], stdout=log, stderr=subprocess.STDOUT, timeout=60).returncode
+        except subprocess.TimeoutExpired:
+            rc = None
+        log.seek(0)
+        out = log.read().decode(errors="replace")
+    assert rc in (None, 0), (rc, out[-800:])
+    assert "rror" not in out and "failed" not in out.lower(), out[-800:]
