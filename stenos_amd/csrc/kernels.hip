@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 				atomicOr(a.status, DECODE_STATUS_INVALID);
 			return;
 		}
-		copy_g2g_wide(out, payload, csize);
+		copy_g2g_wide<STENOS_DECODE_COPY_ROUNDS>(out, payload, csize); // (this kernel has registers to spare: more loads in flight per trip)
 	}
 	else if (code >= 2 && code <= 5) { // zstd based codes are finished by the host
 		if (threadIdx.x == 0)

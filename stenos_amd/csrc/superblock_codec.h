@@ -359,6 +359,10 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 #define STENOS_COPY_ROUNDS 4
 #endif
 constexpr uint32_t COPY_ROUNDS = STENOS_COPY_ROUNDS;
+#ifndef STENOS_DECODE_COPY_ROUNDS
+#define STENOS_DECODE_COPY_ROUNDS 4
+#endif
+template <uint32_t ROUNDS = COPY_ROUNDS>
 WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 {
 	const U32 lane = lane_id();
@@ -371,13 +375,13 @@ WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 	const uint32_t groups = (n - h) >> 4;
 	uint8_t* d = dst + h;
 	const uint8_t* s = src + h;
-	for (uint32_t o = 0; o < groups; o += 64 * COPY_ROUNDS) {
-		U128 a[COPY_ROUNDS];
-		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+	for (uint32_t o = 0; o < groups; o += 64 * ROUNDS) {
+		U128 a[ROUNDS];
+		for (uint32_t q = 0; q < ROUNDS; ++q) {
 			const U32 k = U32(o + 64 * q) + lane;
 			a[q] = gld128_unaligned(s, k * 16u, k < U32(groups));
 		}
-		for (uint32_t q = 0; q < COPY_ROUNDS; ++q) {
+		for (uint32_t q = 0; q < ROUNDS; ++q) {
 			const U32 k = U32(o + 64 * q) + lane;
 			gst128(d, k * 16u, a[q], k < U32(groups));
 		}

@@ -53,7 +53,7 @@ def test_lanes_frame_equals_single_device_frame(lib, kind, T, mib, threads):
         lib.stenos_set_threads(c, th)
         back = np.full(data.nbytes + 64, 0x5A, dtype=np.uint8)
         assert lib.stenos_decompress_generic(c, np_ptr(fn), T, rn, np_ptr(back), data.nbytes) == data.nbytes
-        assert lib.stenos_hip_last_devices(c) == th
+        assert lib.stenos_hip_last_devices(c) == (1 if kind == "rand" else th)  # (a frame of copies is decoded by the host: no device at all)
         lib.stenos_destroy_context(c)
         assert np.array_equal(back[: data.nbytes], data.view(np.uint8).ravel())
         assert (back[data.nbytes:] == 0x5A).all()

@@ -14,7 +14,7 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w") as f:
     json.dump(json.loads(line), f, indent=1)
 rows = list(csv.reader(open(os.path.join(ROOT, "gpurun_out", f"{tag}_kernel_stats_raw.csv"))))
 with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-full-entropy  (MI355X, 8 GiB int32 rand12, 2 warmup + 10 timed steps; bench.py runs one more untimed compression for the sharded / parity legs only when asked)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-full-entropy --no-other-configs  (MI355X, 8 GiB int32 rand12, 2 warmup + 10 timed steps; bench.py runs one more untimed compression for the sharded / parity legs only when asked)\n")
     f.write("# rows of this repo's kernels and the runtime's copy/fill kernels; torch's data-generation kernels are left out\n")
     w = csv.writer(f)
     w.writerow(rows[0])
