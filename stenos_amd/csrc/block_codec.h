@@ -175,6 +175,16 @@ WV_FN PlaneRegs load_plane_regs(Lds lds, uint32_t in, uint32_t T, uint32_t g)
 			e2 = e.z;
 			e3 = e.w;
 		}
+		else if (T == 8) {
+			// the lane's four doubles are 32 consecutive bytes: two 16-byte reads (lanes 8 apart share banks: 2-way) instead
+			// of four dword reads at a stride of 32 bytes (lanes 4 apart share a bank: 8-way conflicts on every one of them)
+			const U32 a = U32(in) + lane_id() * 32u;
+			const U128 lo = lds_ld128(lds, a), hi = lds_ld128(lds, a + 16u);
+			e0 = g ? lo.y : lo.x;
+			e1 = g ? lo.w : lo.z;
+			e2 = g ? hi.y : hi.x;
+			e3 = g ? hi.w : hi.z;
+		}
 		else {
 			U32 a = U32(in + g) + lane_id() * (4u * T);
 			e0 = lds_ld32(lds, a);

@@ -1832,8 +1832,11 @@ size_t compress_timed(stenos_context* ctx, const uint8_t* src, size_t T, size_t 
 		const size_t n = bytes - pos < slice ? bytes - pos : slice;
 		const double left = budget - std::chrono::duration<double>(clock::now() - start).count();
 		const double rest = (double)(bytes - pos - n) / rate[0]; // what copying everything behind this slice takes
+		// the first device call of a context also pays for the runtime's start, the code object and the buffers: a tight
+		// budget on a cold context is better spent copying
+		const double cold = ctx->in.cap == 0 && ctx->slots.cap == 0 ? 0.25 : 0.0;
 		int level = 0;
-		if (top >= 1 && left > 0 && (double)n / rate[1] + rest <= left)
+		if (top >= 1 && left > 0 && (double)n / rate[1] + rest + cold <= left)
 			level = 1;
 		if (level == 1 && top >= 2 && zstd().ok && (double)n / rate[2] + rest <= left * 0.5)
 			level = 2;

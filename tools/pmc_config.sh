@@ -12,6 +12,6 @@ P2="SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_I
 i=1
 for P in "$P1" "$P2"; do
   rm -rf $OUT/p$i
-  timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config $CFG $KIND --gib 8 --steps 1 --warmup 0 --no-cpu-baseline --no-full-entropy > $OUT/p$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config $CFG $KIND --gib 8 --steps 1 --warmup 0 --no-cpu-baseline --no-full-entropy --no-other-configs > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
