@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from _libs import (STAT_LZ, STAT_PARTIAL, STAT_PLANE_TYPE, STAT_ROW_HDR, STAT_SB_CODE, frame_stats, has_error,
+from _libs import (STAT_COUNT, STAT_LZ, STAT_PARTIAL, STAT_PLANE_TYPE, STAT_ROW_HDR, STAT_SB_CODE, frame_stats, has_error,
                    np_ptr, oracle_compress)
 from stenos_amd.datagen import generate
 
@@ -43,7 +43,7 @@ def test_oracle_matches_golden(oracle, entry):
 def test_golden_covers_the_bitstream(oracle):
     """Every plane type, every row header the encoder can emit, LZ blocks, partial blocks and the
     superblock codes 1/2/6 occur in the golden set."""
-    total = np.zeros(30, dtype=np.uint64)
+    total = np.zeros(STAT_COUNT, dtype=np.uint64)
     for e in MANIFEST:
         if e["n"] > 40000 and e["kind"] != "sorted_i32":
             continue
