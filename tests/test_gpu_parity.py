@@ -404,3 +404,51 @@ def test_int32_kinds_through_the_fused_kernel(lib, ctx, oracle):
         r1, ref = oracle_compress(oracle, data, 4, 1)
         r2, frame = gpu_compress(lib, ctx, data, 4, 1)
         assert r1 == r2 and np.array_equal(ref, frame), kind
+
+
+def test_distinct_contexts_on_concurrent_threads(lib, oracle):
+    """stenos.h: a context must not be used concurrently, distinct contexts may (stenos.cpp:762-764).  Four threads, a
+    context each, different data and levels, host-pointer calls at the same time: every frame equals the frame the same
+    call produces alone and decodes to its input."""
+    import threading
+
+    jobs = [("rand12", 4, 3_000_001, 1), ("walk", 2, 2_500_003, 1), ("sine", 8, 600_001, 2), ("mixed", 3, 900_001, 1), ("smooth8", 1, 2_000_000, 3), ("sorted_i32", 4, 1_000_000, 1)]
+    datas = [generate(k, T, n, 21 + i).view(np.uint8).ravel() for i, (k, T, n, _) in enumerate(jobs)]
+
+    def once(i, out):
+        _, T, _, level = jobs[i]
+        d = datas[i]
+        c = lib.stenos_make_context()
+        lib.stenos_set_level(c, level)
+        buf = np.zeros(lib.stenos_bound(d.nbytes), dtype=np.uint8)
+        frames = []
+        for _ in range(3):
+            r = lib.stenos_compress_generic(c, np_ptr(d), T, d.nbytes, np_ptr(buf), buf.nbytes)
+            assert not has_error(r), hex(r)
+            back = np.zeros(d.nbytes, dtype=np.uint8)
+            assert lib.stenos_decompress_generic(c, np_ptr(buf), T, r, np_ptr(back), d.nbytes) == d.nbytes
+            assert np.array_equal(back, d)
+            frames.append(buf[:r].copy())
+        lib.stenos_destroy_context(c)
+        out[i] = frames
+
+    alone = {}
+    for i in range(len(jobs)):
+        once(i, alone)
+    together, errors = {}, []
+
+    def guarded(i):
+        try:
+            once(i, together)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=guarded, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(jobs)):
+        for f in together[i]:
+            assert np.array_equal(f, alone[i][0]), jobs[i]
