@@ -347,3 +347,52 @@ def test_fused_path_wide_batches(oracle, emul, T, dtype):
         r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), out.nbytes, 1)
         assert emul.emul_last_fused() > 0
         assert r1 == r2 and np.array_equal(ref, out[:r2]), trial
+
+
+@pytest.mark.parametrize("T,dtype", [(2, np.uint16), (4, np.uint32)])
+def test_fused_path_planes_of_noise(oracle, emul, T, dtype):
+    """Blocks whose byte planes are, independently, constant, noise, noise of a few bits, a slow walk or runs -- so that RAW
+    planes stand in front of, behind and between compressible planes and constant ones, blocks consist of RAW planes only,
+    and batches of the slot encoder break in every place -- through the fused path against the oracle."""
+    from _libs import oracle_compress
+
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    emul.emul_last_fused.restype = c_size_t
+    emul.emul_set_fused(1)
+    emul.emul_set_slots(1)
+    rng = np.random.default_rng(11 + T)
+    for trial in range(8):
+        stationary = trial % 4 != 3  # both a steady and a changing mix of planes
+        kinds = rng.integers(0, 5, T)
+        if stationary:
+            kinds[int(rng.integers(0, T))] = 1  # at least one plane of noise
+        parts = []
+        for b in range(int(rng.integers(300, 650))):
+            if not stationary or rng.integers(0, 40) == 0:
+                kinds = rng.integers(0, 5, T)
+                if stationary:
+                    kinds[int(rng.integers(0, T))] = 1
+            v = np.zeros(256, dtype=np.uint64)
+            for k in range(T):
+                kind = int(kinds[k])
+                if kind == 0:
+                    pl = np.full(256, int(rng.integers(0, 256)), dtype=np.uint64)
+                elif kind == 1:
+                    pl = rng.integers(0, 256, 256, dtype=np.uint64)
+                elif kind == 2:
+                    pl = rng.integers(0, 16, 256, dtype=np.uint64) + int(rng.integers(0, 200))
+                elif kind == 3:
+                    pl = (np.cumsum(rng.integers(-3, 4, 256)) + 128).astype(np.uint64) & 0xFF
+                else:
+                    pl = np.repeat(rng.integers(0, 256, 32, dtype=np.uint64), 8)
+                v |= pl << np.uint64(8 * k)
+            parts.append(v)
+        if trial % 3 == 0:
+            parts.append(rng.integers(0, 256, int(rng.integers(1, 256)), dtype=np.uint64))
+        data = np.concatenate(parts).astype(dtype).view(np.uint8)
+        r1, ref = oracle_compress(oracle, data, T, 1)
+        out = np.zeros(oracle.so_bound(data.nbytes) + 4096, dtype=np.uint8)
+        r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), out.nbytes, 1)
+        assert emul.emul_last_fused() > 0
+        assert r1 == r2 and np.array_equal(ref, out[:r2]), trial
