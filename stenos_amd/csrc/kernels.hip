@@ -10,9 +10,7 @@
 //                      the plan flagged (normally none or the last; pipeline.h)
 //   pack_frame         four wavefronts per superblock, destination-ordered gather of the block slots,
 //                      frame header (stenos.cpp:862-874)
-// Decode pipeline:
-//   walk_superblocks   (only without an index) serial walk of the [code][csize:3] chain (stenos.cpp:1129-1134)
-//   decode_superblocks one wavefront per superblock (block_compress.h:2088-2175)
+// The decode pipeline lives in decode_kernels.hip (a translation unit with compiler options of its own).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -208,7 +206,11 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 			const uint8_t* from = j.src + (s * j.bps + b0) * (uint64_t)(256 * T);
 			uint8_t* to = stage_w + (uint64_t)parity * FUSED_WAVES * run_cap;
 			for (uint32_t attempt = 0;; ++attempt) {
+#ifdef STENOS_EXP_MEASURE_ONLY // (timing experiment, no frames: loads, analysis and placement only)
+				const bool measure = true;
+#else
 				const bool measure = guess_copy && attempt == 0;
+#endif
 				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to);
 				if ((threadIdx.x & 63u) == 0)
 					runs[w] = n;
@@ -217,7 +219,11 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 					run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(runs[k]);
 				uint32_t code;
 				const uint32_t bytes = fused_superblock_size(j, run_size, &code);
+#ifndef STENOS_EXP_MEASURE_ONLY
 				if (measure && code != 6) { // it does compress: once more, with the bytes
+#else
+				if (false) {
+#endif
 					__syncthreads(); // (everyone has read the sizes before they are written again)
 					continue;
 				}
@@ -233,8 +239,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 			const uint64_t off = chain_wait(j, prev);
 			if (off == CHAIN_FAILED)
 				shared[2] = 1;
+#ifndef STENOS_EXP_NO_STORE // (timing experiment, wrong frames: what the staging read and the frame write cost)
 			else
 				fused_store(j, prev, w, off, prev_run, stage_w + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap);
+#endif
 		}
 		if (!work)
 			return;
@@ -305,74 +313,6 @@ __global__ __launch_bounds__(64) void resolve_frame(FrameJob j)
 }
 
 __global__ __launch_bounds__(64) void pack_frame(FrameJob j, uint64_t s_begin) { pack_superblock(g_lds, j, s_begin + blockIdx.x / PACK_WAVES, blockIdx.x % PACK_WAVES); }
-
-// Serial walk of the superblock chain by one lane: off[s] = byte offset of superblock s's header.
-__global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* __restrict__ off,
-				 uint32_t* __restrict__ status)
-{
-	if (threadIdx.x != 0 || blockIdx.x != 0)
-		return;
-	uint64_t p = first;
-	for (uint64_t s = 0; s < nsb; ++s) {
-		if (p + 4 > size) { // stenos.cpp:1126-1127
-			atomicOr(status, DECODE_STATUS_TRUNCATED);
-			for (; s <= nsb; ++s) off[s] = size;
-			return;
-		}
-		off[s] = p;
-		uint32_t csize = (uint32_t)frame[p + 1] | ((uint32_t)frame[p + 2] << 8) | ((uint32_t)frame[p + 3] << 16);
-		p += 4 + (uint64_t)csize;
-	}
-	off[nsb] = p;
-	if (p > size)
-		atomicOr(status, DECODE_STATUS_TRUNCATED);
-}
-
-template <uint32_t TT>
-__global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
-{
-	const uint32_t T = TT ? TT : a.T;
-	const uint64_t s = a.sb_ids ? a.sb_ids[blockIdx.x] : blockIdx.x;
-	const U32 lane = lane_id();
-	const uint64_t p = a.sb_off[blockIdx.x];
-	if (p > a.size || a.size - p < 4) { // (written without sums: an index entry may hold anything)
-		if (threadIdx.x == 0)
-			atomicOr(a.status, DECODE_STATUS_TRUNCATED);
-		return;
-	}
-	const uint32_t code = a.frame[p];
-	const uint32_t csize = (uint32_t)a.frame[p + 1] | ((uint32_t)a.frame[p + 2] << 8) | ((uint32_t)a.frame[p + 3] << 16);
-	const uint64_t begin = s * (uint64_t)a.sb_bytes;
-	const uint32_t dsize = (uint32_t)((a.total_bytes - begin) < a.sb_bytes ? (a.total_bytes - begin) : a.sb_bytes);
-	if (a.size - p - 4 < csize) { // stenos.cpp:1133-1134
-		if (threadIdx.x == 0)
-			atomicOr(a.status, DECODE_STATUS_TRUNCATED);
-		return;
-	}
-	const uint8_t* payload = a.frame + p + 4;
-	uint8_t* out = a.dst + begin;
-	if (code == 1) {
-		const DecLayout L = make_dec_layout(T);
-		uint32_t r = decode_superblock(g_lds, L, T, payload, csize, out, dsize, TT != 0);
-		if (r == DEC_ERROR && threadIdx.x == 0)
-			atomicOr(a.status, DECODE_STATUS_INVALID);
-	}
-	else if (code == 6) { // stenos.cpp:741-746
-		if (csize != dsize) {
-			if (threadIdx.x == 0)
-				atomicOr(a.status, DECODE_STATUS_INVALID);
-			return;
-		}
-		copy_g2g_wide<STENOS_DECODE_COPY_ROUNDS>(out, payload, csize); // (this kernel has registers to spare: more loads in flight per trip)
-	}
-	else if (code >= 2 && code <= 5) { // zstd based codes are finished by the host
-		if (threadIdx.x == 0)
-			atomicOr(a.status, DECODE_STATUS_HOST_CODES);
-	}
-	else if (threadIdx.x == 0)
-		atomicOr(a.status, DECODE_STATUS_INVALID);
-	(void)lane;
-}
 
 } // namespace
 
@@ -528,33 +468,4 @@ hipError_t stenos_k_launch_pack(const FrameJob& j, uint64_t s_begin, uint64_t s_
 		return hipSuccess;
 	hipLaunchKernelGGL(pack_frame, dim3((uint32_t)((s_end - s_begin) * PACK_WAVES)), dim3(64), pack_lds_bytes(j.bps), stream, j, s_begin);
 	return hipGetLastError();
-}
-
-hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream)
-{
-	hipLaunchKernelGGL(walk_superblocks, dim3(1), dim3(64), 0, stream, frame, size, first, nsb, off, status);
-	return hipGetLastError();
-}
-
-template <uint32_t TT>
-static hipError_t launch_decode_t(const DecodeArgs& a, hipStream_t stream)
-{
-	const size_t lds = stenos_k_decode_lds_bytes(a.T);
-	hipError_t e = hipFuncSetAttribute((const void*)decode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	if (e != hipSuccess)
-		return e;
-	hipLaunchKernelGGL(decode_superblocks<TT>, dim3((uint32_t)a.nsb), dim3(64), lds, stream, a);
-	return hipGetLastError();
-}
-
-hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream)
-{
-	if (a.T > STENOS_K_LDS_MAX_T)
-		return stenos_kw_launch_decode(a, stream);
-	switch (a.T) {
-		case 2: return launch_decode_t<2>(a, stream);
-		case 4: return launch_decode_t<4>(a, stream);
-		case 8: return launch_decode_t<8>(a, stream);
-		default: return launch_decode_t<0>(a, stream);
-	}
 }

@@ -12,6 +12,7 @@ namespace codec {
 
 // ---- HBM <-> LDS copies by one wave ---------------------------------------------------------------
 
+#ifdef WV_PREDICATE_BRANCHES // (the encoders: predicates as branches, wavevec.h)
 // g must be 16-byte aligned; never reads past g + n
 WV_FN void copy_g2l(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
 {
@@ -51,6 +52,56 @@ WV_FN void store_block(uint8_t* g, Lds lds, uint32_t ldsoff, uint32_t n)
 	Pred t = lane < U32(n - full);
 	gst8(g, U32(full) + lane, lds_ld8(lds, U32(ldsoff + full) + sel(t, lane, U32(0u))), t);
 }
+
+#else
+// The copies below take no predicate: a lane beyond the end repeats the last group (or byte) -- the same bytes to the same
+// place -- so every access is an ordinary one the compiler schedules and waits for as usual, and there is no divergent
+// branch around it (wavevec.h, "Predicated memory accesses without a branch").
+
+// g must be 16-byte aligned; never reads past g + n
+WV_FN void copy_g2l(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t full = n & ~15u;
+	for (uint32_t o = 0; o < full; o += 1024) {
+		const U32 off = umin(U32(o) + lane * 16u, U32(full - 16u));
+		lds_st128(lds, U32(ldsoff) + off, gld128(g, off, pred_all(true)), pred_all(true));
+	}
+	if (n - full) {
+		const U32 k = U32(full) + umin(lane, U32(n - full - 1u));
+		lds_st8(lds, U32(ldsoff) + k, gld8(g, k, pred_all(true)), pred_all(true));
+	}
+}
+// any alignment of g
+WV_FN void load_block(Lds lds, uint32_t ldsoff, const uint8_t* g, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t full = n & ~15u;
+	for (uint32_t o = 0; o < full; o += 1024) {
+		const U32 off = umin(U32(o) + lane * 16u, U32(full - 16u));
+		lds_st128(lds, U32(ldsoff) + off, gld128_unaligned(g, off, pred_all(true)), pred_all(true));
+	}
+	if (n - full) {
+		const U32 k = U32(full) + umin(lane, U32(n - full - 1u));
+		lds_st8(lds, U32(ldsoff) + k, gld8(g, k, pred_all(true)), pred_all(true));
+	}
+}
+// LDS image -> HBM, never writes past g + n
+WV_FN void store_block(uint8_t* g, Lds lds, uint32_t ldsoff, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t full = n & ~15u;
+	for (uint32_t o = 0; o < full; o += 1024) {
+		const U32 off = umin(U32(o) + lane * 16u, U32(full - 16u));
+		gst128_unaligned(g, off, lds_ld128(lds, U32(ldsoff) + off), pred_all(true));
+	}
+	if (n - full) {
+		const U32 k = U32(full) + umin(lane, U32(n - full - 1u));
+		gst8(g, k, lds_ld8(lds, U32(ldsoff) + k), pred_all(true));
+	}
+}
+
+#endif
 
 // ---- encode side -----------------------------------------------------------------------------------
 
@@ -362,6 +413,7 @@ constexpr uint32_t COPY_ROUNDS = STENOS_COPY_ROUNDS;
 #ifndef STENOS_DECODE_COPY_ROUNDS
 #define STENOS_DECODE_COPY_ROUNDS 4
 #endif
+#ifdef WV_PREDICATE_BRANCHES
 template <uint32_t ROUNDS = COPY_ROUNDS>
 WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 {
@@ -393,6 +445,37 @@ WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
 	}
 }
 
+#else
+template <uint32_t ROUNDS = COPY_ROUNDS>
+WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)
+{
+	const U32 lane = lane_id();
+	const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+	const uint32_t h = head < n ? head : n;
+	if (h) // (loads: lanes beyond the end repeat the last byte / group, see copy_g2l; stores: predicated, not waited for)
+		gst8_streamed(dst, lane, gld8(src, umin(lane, U32(h - 1u)), pred_all(true)), lane < U32(h));
+	const uint32_t groups = (n - h) >> 4;
+	uint8_t* d = dst + h;
+	const uint8_t* s = src + h;
+	for (uint32_t o = 0; o < groups; o += 64 * ROUNDS) {
+		U128 a[ROUNDS];
+		for (uint32_t q = 0; q < ROUNDS; ++q) // (a round that lies beyond the end altogether is a scalar branch away)
+			if (o + 64 * q < groups) {
+				const U32 k = umin(U32(o + 64 * q) + lane, U32(groups - 1u));
+				a[q] = gld128_unaligned(s, k * 16u, pred_all(true));
+			}
+		for (uint32_t q = 0; q < ROUNDS; ++q)
+			if (o + 64 * q < groups) {
+				const U32 k = U32(o + 64 * q) + lane;
+				gst128_streamed(d, k * 16u, a[q], k < U32(groups));
+			}
+	}
+	const uint32_t done = h + groups * 16;
+	if (n - done)
+		gst8_streamed(dst + done, lane, gld8(src + done, umin(lane, U32(n - done - 1u)), pred_all(true)), lane < U32(n - done));
+}
+
+#endif
 // The tail of a superblock payload: n < 256*T bytes -> [254] + partial block (block_compress.h:1277-1293).
 // info.full is unused for tails; info.need is the capacity requirement counted from the 254 byte.
 WV_FN BlockInfo encode_tail_job(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t n, uint8_t* slot)

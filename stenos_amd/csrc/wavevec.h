@@ -439,6 +439,8 @@ WV_FN void gst128(uint8_t* g, const U32& off, const U128& v, const Pred& p)
 		}
 }
 WV_FN void gst128_unaligned(uint8_t* g, const U32& off, const U128& v, const Pred& p) { gst128(g, off, v, p); }
+WV_FN void gst128_streamed(uint8_t* g, const U32& off, const U128& v, const Pred& p) { gst128(g, off, v, p); }
+WV_FN void gst8_streamed(uint8_t* g, const U32& off, const U32& v, const Pred& p) { gst8(g, off, v, p); }
 WV_FN void gst64_unaligned(uint8_t* g, const U32& off, const U32& lo, const U32& hi, const Pred& p) { gst64(g, off, lo, hi, p); }
 // wave-uniform scalar accesses to global memory
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *p; }
@@ -653,6 +655,28 @@ WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
 	hi = *(const uint32_t*)(m + (a & ~3u) + 4);
 }
 #endif
+// Predicated memory accesses without a branch.  `if (p) store` is a divergent branch, and one divergent branch anywhere
+// inside a loop makes the compiler structurize every wave-uniform `if` of that loop as well (conditions kept as lane
+// masks, s_cselect_b64 / s_and_b64 / s_cbranch_vccnz instead of s_cmp / s_cbranch_scc, flags carried between flow
+// blocks): a third of the scalar instructions of the block loops.  So the predicate goes into the execution mask for the
+// one instruction, in a single asm statement the compiler cannot interleave with anything.  LDS executes a wave's
+// accesses in order, so stores the compiler does not count need no wait; global accesses issued here are waited for
+// inside the statement (they are the rare ones: the hot loops clamp their addresses instead, see superblock_codec.h).
+// The low 32 bits of a flat address of LDS are the LDS offset.
+WV_FN uint32_t lds_offset(Lds m, U32 a) { return (uint32_t)(uintptr_t)m + a; }
+typedef uint32_t wv_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wv_u2 __attribute__((ext_vector_type(2)));
+#define WV_MASKED(instr, mask, ...)                                                                                    \
+	do {                                                                                                              \
+		uint64_t wv_save;                                                                                               \
+		asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t" instr "\n\ts_mov_b64 exec, %0"                 \
+			     : "=&s"(wv_save)                                                                                       \
+			     : "s"(mask), __VA_ARGS__                                                                               \
+			     : "memory", "scc");                                                                                    \
+	} while (0)
+#if defined(STENOS_WIDE) || defined(WV_PREDICATE_BRANCHES)
+// (STENOS_WIDE: the scratch is global memory there; WV_PREDICATE_BRANCHES: the encoders, which are faster with branches,
+// csrc/Makefile)
 WV_FN void lds_st32(Lds m, U32 a, U32 v, Pred p)
 {
 	if (p) *(uint32_t*)(m + (a & ~3u)) = v;
@@ -671,27 +695,106 @@ WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
 {
 	return p ? __hip_atomic_fetch_add((uint32_t*)(m + (a & ~3u)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
 }
+#else
+WV_FN void lds_st32(Lds m, U32 a, U32 v, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		*(uint32_t*)(m + (a & ~3u)) = v;
+	else
+		WV_MASKED("ds_write_b32 %2, %3", ballot(p), "v"(lds_offset(m, a & ~3u)), "v"(v));
+}
+WV_FN void lds_st8(Lds m, U32 a, U32 v, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		m[a] = (uint8_t)v;
+	else
+		WV_MASKED("ds_write_b8 %2, %3", ballot(p), "v"(lds_offset(m, a)), "v"(v));
+}
+WV_FN U32 lds_cas32(Lds m, U32 a, U32 expect, U32 v, Pred p)
+{
+	// (ds_cmpst_rtn_b32 vdst, addr, compare, new value; lanes that stay out get `expect` back, as if the swap had happened)
+	uint32_t e = expect;
+	uint64_t save;
+	asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %2\n\tds_cmpst_rtn_b32 %0, %3, %4, %5\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %1"
+		     : "+v"(e), "=&s"(save)
+		     : "s"(ballot(p)), "v"(lds_offset(m, a & ~3u)), "v"(expect), "v"(v)
+		     : "memory", "scc");
+	return e; // the value found (== expect when the swap happened)
+}
+WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
+{
+	uint32_t r = 0;
+	uint64_t save;
+	asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %2\n\tds_add_rtn_u32 %0, %3, %4\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %1"
+		     : "+v"(r), "=&s"(save)
+		     : "s"(ballot(p)), "v"(lds_offset(m, a & ~3u)), "v"(v)
+		     : "memory", "scc");
+	return r;
+}
+#endif
 // OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
 // at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)
 WV_FN U32 lds_or_rtn32(Lds m, U32 a, U32 v) { return __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_FN void lds_or32_all(Lds m, U32 a, U32 v) { __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_FN void lds_or32(Lds m, U32 a, U32 v, Pred p)
 {
+#ifdef WV_PREDICATE_BRANCHES
 	__hip_atomic_fetch_or((uint32_t*)(m + (p ? (a & ~3u) : lane_id() * 4u)), p ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+	const U32 own = lane_id() * 4u; // (outside the selection: lane_id() hides an asm statement, which would turn it into a branch)
+	__hip_atomic_fetch_or((uint32_t*)(m + (p ? (a & ~3u) : own)), p ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
 }
 
 // ---- global memory ----
 struct U128 {
 	U32 x, y, z, w;
 };
+// predicated global loads: the lanes that stay out read nothing and get 0
+#define WV_MASKED_LOAD(instr, dst, mask, ptr)                                                                          \
+	do {                                                                                                              \
+		uint64_t wv_save;                                                                                               \
+		asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %2\n\t" instr " %0, %3, off\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %1" \
+			     : "+v"(dst), "=&s"(wv_save)                                                                            \
+			     : "s"(mask), "v"(ptr)                                                                                  \
+			     : "memory", "scc");                                                                                    \
+	} while (0)
+#define WV_MASKED_STORE(instr, mask, ptr, data)                                                                        \
+	do {                                                                                                              \
+		uint64_t wv_save;                                                                                               \
+		asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t" instr " %2, %3, off\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %0" \
+			     : "=&s"(wv_save)                                                                                       \
+			     : "s"(mask), "v"(ptr), "v"(data)                                                                       \
+			     : "memory", "scc");                                                                                    \
+	} while (0)
+#ifdef WV_PREDICATE_BRANCHES
 WV_FN U32 gld8(const uint8_t* g, U32 off, Pred p) { return p ? (U32)g[off] : 0u; }
 WV_FN U32 gld32(const uint8_t* g, U32 off, Pred p) { return p ? *(const uint32_t*)(g + off) : 0u; }
+#else
+WV_FN U32 gld8(const uint8_t* g, U32 off, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		return (U32)g[off];
+	uint32_t r = 0;
+	WV_MASKED_LOAD("global_load_ubyte", r, ballot(p), g + off);
+	return r;
+}
+WV_FN U32 gld32(const uint8_t* g, U32 off, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		return *(const uint32_t*)(g + off);
+	uint32_t r = 0;
+	WV_MASKED_LOAD("global_load_dword", r, ballot(p), g + off);
+	return r;
+}
+#endif
 WV_FN void gld64(const uint8_t* g, U32 off, U32& lo, U32& hi)
 {
 	uint2 v = *(const uint2*)(g + off);
 	lo = v.x;
 	hi = v.y;
 }
+#ifdef WV_PREDICATE_BRANCHES
 WV_FN U128 gld128(const uint8_t* g, U32 off, Pred p)
 {
 	U128 r = { 0u, 0u, 0u, 0u };
@@ -712,6 +815,31 @@ WV_FN U128 gld128_unaligned(const uint8_t* g, U32 off, Pred p)
 	}
 	return r;
 }
+#else
+// 16 bytes from any byte address (gfx9 and later serve unaligned global accesses in hardware)
+WV_FN U128 gld128_unaligned(const uint8_t* g, U32 off, Pred p)
+{
+	typedef uint4 __attribute__((aligned(1))) uint4_u;
+	if (__builtin_constant_p(p) && p) {
+		uint4 v = *(const uint4_u*)(g + off);
+		U128 r = { v.x, v.y, v.z, v.w };
+		return r;
+	}
+	wv_u4 d = { 0u, 0u, 0u, 0u };
+	WV_MASKED_LOAD("global_load_dwordx4", d, ballot(p), g + off);
+	U128 r = { d.x, d.y, d.z, d.w };
+	return r;
+}
+WV_FN U128 gld128(const uint8_t* g, U32 off, Pred p)
+{
+	if (__builtin_constant_p(p) && p) {
+		uint4 v = *(const uint4*)(g + off);
+		U128 r = { v.x, v.y, v.z, v.w };
+		return r;
+	}
+	return gld128_unaligned(g, off, p);
+}
+#endif
 WV_FN void gld64_unaligned(const uint8_t* g, U32 off, U32& lo, U32& hi)
 {
 	typedef uint2 __attribute__((aligned(1))) uint2_u;
@@ -719,6 +847,7 @@ WV_FN void gld64_unaligned(const uint8_t* g, U32 off, U32& lo, U32& hi)
 	lo = v.x;
 	hi = v.y;
 }
+#ifdef WV_PREDICATE_BRANCHES
 WV_FN void gst8(uint8_t* g, U32 off, U32 v, Pred p)
 {
 	if (p) g[off] = (uint8_t)v;
@@ -745,26 +874,113 @@ WV_FN void gst64_unaligned(uint8_t* g, U32 off, U32 lo, U32 hi, Pred p)
 	typedef uint2 __attribute__((aligned(1))) uint2_u;
 	if (p) *(uint2_u*)(g + off) = make_uint2(lo, hi);
 }
+WV_FN void gst128_streamed(uint8_t* g, U32 off, const U128& v, Pred p) { gst128(g, off, v, p); }
+WV_FN void gst8_streamed(uint8_t* g, U32 off, U32 v, Pred p) { gst8(g, off, v, p); }
+#else
+WV_FN void gst8(uint8_t* g, U32 off, U32 v, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		g[off] = (uint8_t)v;
+	else
+		WV_MASKED_STORE("global_store_byte", ballot(p), g + off, v);
+}
+WV_FN void gst32(uint8_t* g, U32 off, U32 v, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		*(uint32_t*)(g + off) = v;
+	else
+		WV_MASKED_STORE("global_store_dword", ballot(p), g + off, v);
+}
+WV_FN void gst64_unaligned(uint8_t* g, U32 off, U32 lo, U32 hi, Pred p)
+{
+	typedef uint2 __attribute__((aligned(1))) uint2_u;
+	if (__builtin_constant_p(p) && p)
+		*(uint2_u*)(g + off) = make_uint2(lo, hi);
+	else {
+		wv_u2 d = { lo, hi };
+		WV_MASKED_STORE("global_store_dwordx2", ballot(p), g + off, d);
+	}
+}
+WV_FN void gst64(uint8_t* g, U32 off, U32 lo, U32 hi, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		*(uint2*)(g + off) = make_uint2(lo, hi);
+	else
+		gst64_unaligned(g, off, lo, hi, p);
+}
+WV_FN void gst128_unaligned(uint8_t* g, U32 off, const U128& v, Pred p)
+{
+	typedef uint4 __attribute__((aligned(1))) uint4_u;
+	if (__builtin_constant_p(p) && p)
+		*(uint4_u*)(g + off) = make_uint4(v.x, v.y, v.z, v.w);
+	else {
+		wv_u4 d = { v.x, v.y, v.z, v.w };
+		WV_MASKED_STORE("global_store_dwordx4", ballot(p), g + off, d);
+	}
+}
+// The predicated 16-byte store of the hot loops: as above, but nothing waits for it.  The compiler does not count it; its
+// own waits only become more cautious by that (memory operations of a wave complete in order), and the bytes are read
+// again by the same wave or after the kernel only (superblock_codec.h: stream_append, copy_g2g_wide).
+WV_FN uint8_t* uniform_pointer(uint8_t* g) // (a no-op where the compiler knows that all lanes hold the same pointer)
+{
+	const uint64_t a = (uint64_t)g;
+	return (uint8_t*)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32));
+}
+WV_FN void gst128_streamed(uint8_t* g, U32 off, const U128& v, Pred p)
+{
+	// (g is the same for all lanes: a scalar base and a 32-bit lane offset, as the compiler addresses its own stores)
+	wv_u4 d = { v.x, v.y, v.z, v.w };
+	uint64_t save;
+	asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_mov_b64 exec, %0"
+		     : "=&s"(save)
+		     : "s"(ballot(p)), "v"(off), "v"(d), "s"(uniform_pointer(g))
+		     : "memory", "scc");
+}
+WV_FN void gst8_streamed(uint8_t* g, U32 off, U32 v, Pred p)
+{
+	uint64_t save;
+	asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_byte %2, %3, %4\n\ts_mov_b64 exec, %0"
+		     : "=&s"(save)
+		     : "s"(ballot(p)), "v"(off), "v"(v), "s"(uniform_pointer(g))
+		     : "memory", "scc");
+}
+WV_FN void gst128(uint8_t* g, U32 off, const U128& v, Pred p)
+{
+	if (__builtin_constant_p(p) && p)
+		*(uint4*)(g + off) = make_uint4(v.x, v.y, v.z, v.w);
+	else
+		gst128_unaligned(g, off, v, p);
+}
+#endif
 // wave-uniform scalar accesses to global memory (stores by one lane)
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 WV_FN uint32_t gload_uniform8(const uint8_t* p) { return *(const volatile uint8_t*)p; }
 WV_FN uint64_t gload_uniform64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
-WV_FN void gstore_uniform(uint32_t* p, uint32_t v)
+#ifdef WV_PREDICATE_BRANCHES
+WV_FN void status_or(uint32_t* status, uint32_t bits)
 {
-	if (lane_id() == 0) *p = v;
+	if (lane_id() == 0) atomicOr(status, bits);
 }
-WV_FN void gstore_uniform8(uint8_t* p, uint32_t v)
-{
-	if (lane_id() == 0) *p = (uint8_t)v;
-}
-WV_FN void gstore_uniform64(uint64_t* p, uint64_t v)
-{
-	if (lane_id() == 0) *p = v;
-}
+WV_FN void gstore_uniform(uint32_t* p, uint32_t v) { *p = v; }
+WV_FN void gstore_uniform8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
+WV_FN void gstore_uniform64(uint64_t* p, uint64_t v) { *p = v; }
 WV_FN void gmin32(uint32_t* p, uint32_t v)
 {
-	if (lane_id() == 0) atomicMin(p, v);
+	if (v < *p) *p = v;
 }
+#else
+// What one lane of a wavefront does for all, without a branch: the execution mask is 1 for the one instruction.
+// status |= bits, by the first lane
+WV_FN void status_or(uint32_t* status, uint32_t bits) { WV_MASKED_STORE("global_atomic_or", 1ull, (uint8_t*)status, bits); }
+WV_FN void gstore_uniform(uint32_t* p, uint32_t v) { WV_MASKED_STORE("global_store_dword", 1ull, (uint8_t*)p, v); }
+WV_FN void gstore_uniform8(uint8_t* p, uint32_t v) { WV_MASKED_STORE("global_store_byte", 1ull, p, v); }
+WV_FN void gstore_uniform64(uint64_t* p, uint64_t v)
+{
+	wv_u2 d = { (uint32_t)v, (uint32_t)(v >> 32) };
+	WV_MASKED_STORE("global_store_dwordx2", 1ull, (uint8_t*)p, d);
+}
+WV_FN void gmin32(uint32_t* p, uint32_t v) { WV_MASKED_STORE("global_atomic_umin", 1ull, (uint8_t*)p, v); }
+#endif
 WV_FN U128 lds_ld128(Lds m, U32 a)
 {
 #ifdef STENOS_WIDE
@@ -777,7 +993,16 @@ WV_FN U128 lds_ld128(Lds m, U32 a)
 }
 WV_FN void lds_st128(Lds m, U32 a, const U128& v, Pred p)
 {
+#if defined(STENOS_WIDE) || defined(WV_PREDICATE_BRANCHES)
 	if (p) *(uint4*)(m + a) = make_uint4(v.x, v.y, v.z, v.w);
+	return;
+#endif
+	if (__builtin_constant_p(p) && p)
+		*(uint4*)(m + a) = make_uint4(v.x, v.y, v.z, v.w);
+	else {
+		wv_u4 d = { v.x, v.y, v.z, v.w };
+		WV_MASKED("ds_write_b128 %2, %3", ballot(p), "v"(lds_offset(m, a)), "v"(d));
+	}
 }
 } // namespace wv
 #endif
@@ -804,9 +1029,11 @@ WV_FN void lanes_below(uint32_t n, F f)
 {
 #ifdef WV_HOST_EMULATION
 	f(lane_id() < U32(n));
-#else
+#elif defined(WV_PREDICATE_BRANCHES)
 	if (lane_id_plain() < n)
 		f(true);
+#else
+	f(lane_id_plain() < n); // (no divergent region: see the predicated accesses above)
 #endif
 }
 // byte 0 of x in all four bytes (one v_perm_b32)
