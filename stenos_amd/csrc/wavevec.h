@@ -961,12 +961,22 @@ WV_FN void status_or(uint32_t* status, uint32_t bits)
 {
 	if (lane_id() == 0) atomicOr(status, bits);
 }
-WV_FN void gstore_uniform(uint32_t* p, uint32_t v) { *p = v; }
-WV_FN void gstore_uniform8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
-WV_FN void gstore_uniform64(uint64_t* p, uint64_t v) { *p = v; }
+// wave-uniform scalar accesses to global memory (stores by one lane)
+WV_FN void gstore_uniform(uint32_t* p, uint32_t v)
+{
+	if (lane_id() == 0) *p = v;
+}
+WV_FN void gstore_uniform8(uint8_t* p, uint32_t v)
+{
+	if (lane_id() == 0) *p = (uint8_t)v;
+}
+WV_FN void gstore_uniform64(uint64_t* p, uint64_t v)
+{
+	if (lane_id() == 0) *p = v;
+}
 WV_FN void gmin32(uint32_t* p, uint32_t v)
 {
-	if (v < *p) *p = v;
+	if (lane_id() == 0) atomicMin(p, v);
 }
 #else
 // What one lane of a wavefront does for all, without a branch: the execution mask is 1 for the one instruction.

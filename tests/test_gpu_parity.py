@@ -283,6 +283,28 @@ def test_wide_types(lib, oracle, ref_det, T):
     lib.stenos_destroy_context(c)
 
 
+@pytest.mark.parametrize("T,kind,n,seed", [(424, "dict16", 262, 790841817), (424, "dict16", 3 * 256 + 6, 5), (16, "dict16", 5 * 512 + 40, 7), (4, "dict16", 6 * 8192 + 100, 9), (8, "lzmix", 5 * 4096 + 9, 11)])
+def test_capacity_rules_with_several_flagged_superblocks(lib, ctx, oracle, T, kind, n, seed):
+    """Destinations between the frame the block codec could make and stenos_bound: whether a superblock's block stream is
+    accepted depends on the room behind it (block_compress.h:1152-1176, stenos.cpp:424-429), so superblocks are flagged
+    for the replay of the reference's capacity rules (pipeline.h resolve_capacity), the first flagged one found with an
+    atomic minimum over all wavefronts.  A fuzz run found the case in front (two flagged superblocks, bytesoftype 424) when
+    that minimum was not atomic in one build; error or frame, the result must be the oracle's at every capacity."""
+    data = generate(kind, T, n, seed)
+    bound = lib.stenos_bound(data.nbytes)
+    r0, _ = oracle_compress(oracle, data, T, 1)
+    caps = sorted({bound, r0, r0 - 1, r0 - 1000, (r0 * 9) // 10, (r0 * 17) // 20, (r0 * 3) // 4, r0 // 2, bound - 7, bound - 5000})
+    for cap in caps:
+        if cap <= 0:
+            continue
+        for _ in range(3):  # (a race does not show every time)
+            r1, ref = oracle_compress(oracle, data, T, 1, cap)
+            r2, frame = gpu_compress(lib, ctx, data, T, 1, cap)
+            assert has_error(r1) == has_error(r2), (cap, hex(r1), hex(r2))
+            if not has_error(r1):
+                assert r1 == r2 and np.array_equal(ref, frame), cap
+
+
 @pytest.mark.parametrize("T,level", [(72, 2), (100, 3), (300, 5)])
 def test_wide_types_through_the_strategy_layer(lib, ref_det, T, level):
     """levels >= 2 use the same block kernels for their BLOCK / BLOCK_ZSTD candidates (stenos.cpp:546-604)."""
