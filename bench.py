@@ -235,6 +235,28 @@ def roofline(kernel, algo_bytes, kernel_ms, traffic=None, traffic_source=None):
             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kernel_ms, 4)}
 
 
+def device_copy_rate(torch, dev, nbytes=2 << 30, reps=5):
+    """What the runtime's own device-to-device copy reaches on this box (read + written bytes per second): the practical
+    ceiling of a read + write stream, for context next to the fractions of the nominal 8 TB/s.  Never part of `value`."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a.random_(0, 255)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return {"achieved": round(2 * nbytes / (ms / 1e3) / 1e9, 2), "unit": "GB/s", "frac": round(2 * nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": f"torch copy_ of {nbytes >> 30} GiB between two device buffers (the runtime's copy kernel), read + written bytes: the practical ceiling of a read + write stream here"}
+
+
 def reference_prefix_parity(st, torch, src, T, nprefix):
     """Byte-for-byte check at benchmark scale, outside the timed region: the reference's frame of the first `nprefix` bytes
     of the workload (whole superblocks) against the same superblocks of the GPU's frame of the whole array -- superblocks
@@ -365,6 +387,11 @@ def main():
                 traffic = source = None
         roof = roofline("encode_superblocks", algo, r["kenc_ms"], traffic, source)
         roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"]).items() if k in ("achieved", "frac", "kernel_ms")}
+        if world == 1:
+            try:
+                roof["device_copy"] = device_copy_rate(torch, dev)
+            except Exception as ex:  # (context only: never in the way of the line)
+                roof["device_copy"] = {"error": repr(ex)[:200]}
         out = {
             "metric": "encode+decode GB/s (input bytes) at level 1, int32" if T == 4 else f"encode+decode GB/s (input bytes) at level 1, bytesof={T}",
             "value": round(value, 3),
