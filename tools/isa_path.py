@@ -5,7 +5,13 @@ whether it is taken ('t') or falls through ('n'); unconditional branches are fol
 region and per class (vector cheap / vector other / scalar / nop / wait / branch / LDS / vector memory).  When the
 decisions run out, the tool prints the branch it stopped at with some context, so that a path can be worked out
 interactively with the source next to it.
-usage: isa_path.py build/enc4.s <start line> <stop regex> <decisions> [-v]"""
+usage: isa_path.py build/enc4.s <start line> <stop regex> <decisions> [-v]
+Decision strings worked out in round 3 (they hold while the branch structure of the kernel does; the start line is the
+line of the named mark inside the kernel):
+  tools/isa_path_rand12.decisions         encode_superblocks<4>, kernels.hip built as in csrc/Makefile: one pass of two int32
+                                          blocks u & 0xFFF, from MARK load_block to MARK block_end (486 vector + 244 scalar)
+  tools/isa_path_decode_rand12.decisions  decode_superblocks<4>, decode_kernels.hip built as in csrc/Makefile: one such
+                                          block, from MARK dec_block_begin to the next one (93 vector + 88 scalar + 28 branches)"""
 import re
 import sys
 
