@@ -1338,7 +1338,10 @@ WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint3
 			p += 256;
 		}
 	}
-	if (bad || p > end)
+	if (bad) // (two tests, each a scalar compare and branch: as one condition they are put together from lane masks)
+		return DEC_ERROR;
+	WV_NESTED();
+	if (p > end)
 		return DEC_ERROR;
 	if (T == 2)
 		gst64_unaligned(g, lane * 8u, perm_bytes(w[1], w[0], 0x05010400u), perm_bytes(w[1], w[0], 0x07030602u), pred_all(true));

@@ -173,6 +173,13 @@ WV_FN U32 bfe(const U32& x, const U32& off, const U32& width)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (x.l[i] >> (off.l[i] & 31u)) & ((1u << (width.l[i] & 31u)) - 1u);
 	return r;
 }
+// v_alignbit_b32: the low 32 bits of {hi:lo} >> (sh & 31)
+WV_FN U32 funnel_shr(const U32& hi, const U32& lo, const U32& sh)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)((((uint64_t)hi.l[i] << 32) | lo.l[i]) >> (sh.l[i] & 31u));
+	return r;
+}
 // v_dot4_u32_u8: c + a.b0*b.b0 + a.b1*b.b1 + a.b2*b.b2 + a.b3*b.b3
 WV_FN U32 dot4_u8(const U32& a, uint32_t b, const U32& c)
 {
@@ -526,6 +533,7 @@ WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 mul24(U32 a, U32 b) { return __umul24(a, b); } // low 24 bits of both operands, full rate
 WV_FN U32 dot4_u8(U32 a, uint32_t b, U32 c) { return __builtin_amdgcn_udot4(a, b, c, false); } // c + sum of the four byte products
 WV_FN U32 bfe(U32 x, U32 off, U32 width) { return __builtin_amdgcn_ubfe(x, off, width); }
+WV_FN U32 funnel_shr(U32 hi, U32 lo, U32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN U32 perm_bytes_v(U32 hi, U32 lo, U32 selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -1054,9 +1062,7 @@ WV_FN U32 lds_ld32_unaligned(Lds m, const U32& a)
 {
 	U32 lo, hi;
 	lds_ld64(m, a, lo, hi); // reads the aligned dword containing a and the next one
-	U32 sh = (a & 3u) << 3;
-	// (hi:lo) >> sh ; sh in {0,8,16,24}
-	return sel(sh == U32(0u), lo, (lo >> sh) | (hi << (U32(32u) - sh)));
+	return funnel_shr(hi, lo, (a & 3u) << 3); // (hi:lo) >> 0, 8, 16 or 24: one v_alignbit_b32, no case for the aligned address
 }
 
 // OR `nbits` (<= 32) bits of value into the LDS bit stream at bit position bitpos (LSB first);
