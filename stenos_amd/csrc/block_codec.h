@@ -1131,7 +1131,7 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		minv = lds_ld8(win, U32(cur + nh) + sel(emit, ex, U32(0u)));
 	}
 	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins
-		uint32_t mask = win_u16(win, cur + 8);
+		const uint32_t mask = readlane(lds_ld32_unaligned(win, U32(cur + 8)), 0) & 0xFFFFu; // (one window read; the two bytes behind it are literals or slack)
 		uint32_t nlit = 16 - (uint32_t)__builtin_popcount(mask);
 		minslen = 2 + nlit;
 		// min[r] = literal of the last row r' <= r whose mask bit is 0, or 0 when there is none
@@ -1194,9 +1194,16 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		}
 	}
 	// final chain: absolute rows (A=0), delta rows (A=1), rle rows (A = flags)
-	Pred isdelta = !e15 & !erle & (eh >= U32(8u));
-	U32 A = sel(e6 | isdelta, U32(0xFu), sel(e7, f, U32(0u)));
-	U32 Bw = sel(e15, rawv, sel(e6, dv, sel(e7, rlev, packed)));
+	U32 A, Bw;
+	if (!has_rle && !has_raw) { // bit-packed rows only, absolute or delta -- the common shape: nothing to choose between
+		A = sel(eh >= U32(8u), U32(0xFu), U32(0u));
+		Bw = packed;
+	}
+	else {
+		Pred isdelta = !e15 & !erle & (eh >= U32(8u));
+		A = sel(e6 | isdelta, U32(0xFu), sel(e7, f, U32(0u)));
+		Bw = sel(e15, rawv, sel(e6, dv, sel(e7, rlev, packed)));
+	}
 	U32 outw;
 	if (!any(A != U32(0u)))
 		outw = Bw;
