@@ -1379,9 +1379,11 @@ WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint3
 
 // Decode `lines` rows (16 = a full block) of the block whose encoding starts at window offset cur.
 // full: a full block (may be COPY / LZ, planes may be RAW / NORMAL_RLE).
-// g (optional, full blocks of bytesoftype 2, 4, 8 known at compile time): the block's place in HBM; a
-// block made of planes is then written there directly and *direct set, anything else lands in the image as usual.
+// g, direct (optional, together; full blocks of bytesoftype 2, 4, 8 known at compile time): the block's place in HBM; a
+// block made of planes is written there from registers, a copied or mini-LZ block from the image.  Without them the
+// block lands in the image.
 // Returns bytes consumed or DEC_ERROR.
+WV_FN void store_block(uint8_t* g, Lds lds, uint32_t ldsoff, uint32_t n); // (superblock_codec.h)
 WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail, uint32_t lines, bool full, uint8_t* g = nullptr,
 			    bool* direct = nullptr)
 {
@@ -1393,23 +1395,36 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 	// the first four bytes of the encoding in one uniform read: the marker byte / all plane type nibbles up to bytesoftype 8
 	const uint32_t head = readlane(lds_ld32_unaligned(win, U32(cur)), 0);
 	uint32_t first = head & 0xFFu;
-	if (full && first == BLOCK_COPY) { // (:1823-1828)
-		if (avail < 1 + 256 * T)
-			return DEC_ERROR;
-		for (uint32_t o = 0; o < 256 * T; o += 256) {
-			U32 v = lds_ld32_unaligned(win, U32(cur + 1 + o) + lane * 4u);
-			lds_st32(lds, U32(L.img + o) + lane * 4u, v, pred_all(true));
+	if (full && first >= BLOCK_COPY) { // (one test in front of the two markers: a block made of planes passes a single compare)
+		WV_NESTED();
+		if (first == BLOCK_COPY) { // (:1823-1828)
+			if (avail < 1 + 256 * T)
+				return DEC_ERROR;
+			for (uint32_t o = 0; o < 256 * T; o += 256) {
+				U32 v = lds_ld32_unaligned(win, U32(cur + 1 + o) + lane * 4u);
+				lds_st32(lds, U32(L.img + o) + lane * 4u, v, pred_all(true));
+			}
+			wave_sync();
+			if (direct) { // (with a place in HBM every block leaves this function stored: the caller has nothing to ask)
+				store_block(g, lds, L.img, 256 * T);
+				wave_sync();
+			}
+			return 1 + 256 * T;
 		}
-		wave_sync();
-		return 1 + 256 * T;
+		if (first == BLOCK_LZ) { // (:1829-1835)
+			if (T % 4 != 0)
+				return DEC_ERROR;
+			uint32_t n = lz_decode(lds, L, T, cur + 1, avail - 1);
+			if (n == DEC_ERROR)
+				return DEC_ERROR;
+			if (direct) {
+				store_block(g, lds, L.img, 256 * T);
+				wave_sync();
+			}
+			return n + 1;
+		}
 	}
-	if (full && first == BLOCK_LZ) { // (:1829-1835)
-		if (T % 4 != 0)
-			return DEC_ERROR;
-		uint32_t n = lz_decode(lds, L, T, cur + 1, avail - 1);
-		return n == DEC_ERROR ? DEC_ERROR : n + 1;
-	}
-	if (g && full) {
+	if (direct && full) { // (direct is only passed with a place in HBM: its address is known at compile time, g's value is not)
 		*direct = true;
 		if (T == 2)
 			return decode_planes_to<2>(lds, L, cur, avail, head, g);

@@ -584,6 +584,7 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 		wave_sync();
 	};
 
+	uint8_t* to = dst; // where the next block goes
 	for (uint32_t b = 0; b < nblocks; ++b) {
 		WV_MARK("dec_block_begin");
 		uint32_t left = csize - consumed;
@@ -591,15 +592,16 @@ WV_FN uint32_t decode_superblock(Lds lds, const DecLayout& L, uint32_t T, const 
 		ensure(need);
 		WV_MARK("dec_block");
 		bool direct = false;
-		uint32_t n = decode_block(lds, L, T, consumed + mis - wstart, need, 16, true, to_hbm ? dst + (size_t)b * bs : nullptr, &direct);
+		uint32_t n = decode_block(lds, L, T, consumed + mis - wstart, need, 16, true, to_hbm ? to : nullptr, to_hbm ? &direct : nullptr);
 		if (n == DEC_ERROR)
 			return DEC_ERROR;
 		WV_MARK("dec_block_store");
-		if (!direct) {
-			store_block(dst + (size_t)b * bs, lds, L.img, bs);
+		if (!to_hbm) { // (known at compile time: with a place in HBM the block is stored when decode_block returns)
+			store_block(to, lds, L.img, bs);
 			wave_sync();
 		}
 		consumed += n;
+		to += bs;
 	}
 	const uint32_t tail = dsize - nblocks * bs;
 	if (tail) { // [254] + partial block (:1862-1876, 1749-1795)

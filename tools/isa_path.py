@@ -11,7 +11,7 @@ line of the named mark inside the kernel):
   tools/isa_path_rand12.decisions         encode_superblocks<4>, kernels.hip built as in csrc/Makefile: one pass of two int32
                                           blocks u & 0xFFF, from MARK load_block to MARK block_end (486 vector + 244 scalar)
   tools/isa_path_decode_rand12.decisions  decode_superblocks<4>, decode_kernels.hip built as in csrc/Makefile: one such
-                                          block, from MARK dec_block_begin to the next one (82 vector + 79 scalar + 30 branches)"""
+                                          block, from MARK dec_block_begin to the next one (82 vector + 75 scalar + 27 branches)"""
 import re
 import sys
 
