@@ -663,10 +663,12 @@ WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
 	hi = *(const uint32_t*)(m + (a & ~3u) + 4);
 }
 #endif
-// Predicated memory accesses without a branch.  `if (p) store` is a divergent branch, and one divergent branch anywhere
-// inside a loop makes the compiler structurize every wave-uniform `if` of that loop as well (conditions kept as lane
-// masks, s_cselect_b64 / s_and_b64 / s_cbranch_vccnz instead of s_cmp / s_cbranch_scc, flags carried between flow
-// blocks): a third of the scalar instructions of the block loops.  So the predicate goes into the execution mask for the
+// Predicated memory accesses without a branch.  `if (p) store` is a divergent branch, and with one divergent branch
+// anywhere inside a loop the compiler structurizes every wave-uniform `if` of that loop as well -- whatever
+// -structurizecfg-skip-uniform-regions says, which spares regions made of uniform branches only (decode_kernels.hip is
+// compiled with it) -- : conditions kept as lane masks, s_cselect_b64 / s_and_b64 / s_cbranch_vccnz instead of s_cmp /
+// s_cbranch_scc, flags carried between flow blocks; a third of the decoder's scalar instructions were of that kind
+// (tools/divergent_branches.sh lists a kernel's divergent branches).  So the predicate goes into the execution mask for the
 // one instruction, in a single asm statement the compiler cannot interleave with anything.  LDS executes a wave's
 // accesses in order, so stores the compiler does not count need no wait; global accesses issued here are waited for
 // inside the statement (they are the rare ones: the hot loops clamp their addresses instead, see superblock_codec.h).
