@@ -1123,22 +1123,12 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	uint32_t minslen;
 	U32 hdr, minv;
 	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
-	// row payload sizes; rle rows need their mask, found by walking them in order
-	const Pred isrle = act & ((hdr == U32(6u)) | (hdr == U32(7u)));
-	const U32 known = sel(act & !isrle, sel(hdr == U32(15u), U32(16u), (hdr & 7u) * 2u), U32(0u));
-	U32 pre;
-	uint32_t totals;
 	if (type == PLANE_NORMAL) {
-		// one scan for both prefix sums: the rows that send a minimum (at most 16) above bit 16, the payload bytes of the rows
-		// whose size the header tells (at most 256) below
 		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));
-		const U32 both = known | sel(emit, U32(1u << 16), U32(0u));
-		const U32 sc = quads_excl_scan(both);
-		const uint32_t sums = readlane(sc + both, 63); // the last row's inclusive value is the total
-		minslen = sums >> 16;
-		totals = sums & 0xFFFFu;
-		pre = sc & 0xFFFFu;
-		minv = lds_ld8(win, U32(cur + nh) + sel(emit, sc >> 16, U32(0u)));
+		U32 e = sel(emit, U32(1u), U32(0u));
+		U32 ex = quads_excl_scan(e);
+		minslen = readlane(ex + e, 63); // the last row's inclusive value is the total
+		minv = lds_ld8(win, U32(cur + nh) + sel(emit, ex, U32(0u)));
 	}
 	else { // NORMAL_RLE: 8 header bytes, mask16, non-repeated mins
 		const uint32_t mask = readlane(lds_ld32_unaligned(win, U32(cur + 8)), 0) & 0xFFFFu; // (one window read; the two bytes behind it are literals or slack)
@@ -1148,9 +1138,12 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		U32 upto = (~U32(mask)) & ((U32(2u) << row) - 1u) & 0xFFFFu;
 		U32 idx = popc(upto);
 		minv = sel(idx == U32(0u), U32(0u), lds_ld8(win, U32(cur + 10) + sel(idx == U32(0u), U32(0u), idx - 1u)));
-		pre = quads_excl_scan(known);
-		totals = readlane(pre + known, 63);
 	}
+	// row payload sizes; rle rows need their mask, found by walking them in order
+	Pred isrle = act & ((hdr == U32(6u)) | (hdr == U32(7u)));
+	U32 known = sel(act & !isrle, sel(hdr == U32(15u), U32(16u), (hdr & 7u) * 2u), U32(0u));
+	U32 pre = quads_excl_scan(known);
+	const uint32_t totals = readlane(pre + known, 63);
 	U32 rmask(0u), extra(0u);
 	const uint32_t base = cur + nh + minslen;
 	uint64_t todo = ballot(isrle) & 0x1111111111111111ull; // one bit per row: that of its first lane
