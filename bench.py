@@ -15,8 +15,9 @@ With --gpus N every rank owns its own 8 GiB superblock range of an 8*N GiB array
 data-path collective in the timed region); the gather of the compressed segments to rank 0 and the sharded
 decode are run and timed afterwards ("sharded_exchange").
 Outside the timed region at N=1: the reference's CPU path on a 1 GiB prefix ("cpu_baseline"), a byte-for-byte
-comparison of the GPU frame with the reference's frame of that prefix ("parity_prefix_bytes"), and the host-pointer
-ABI end to end ("host_pointer").
+comparison of the GPU frame with the reference's frame of that prefix ("parity_prefix_bytes"), the host-pointer
+ABI end to end ("host_pointer"), the other configurations of BASELINE.json ("other_configs"), and the rate of the
+runtime's own device-to-device copy on the box ("roofline.device_copy": context for the fractions of the nominal peak).
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run.
 Prints ONE JSON line on rank 0.
