@@ -15,11 +15,12 @@ from stenos_amd.datagen import generate
 KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst", "mixed", "lzmix"]
 
 
-@pytest.fixture(scope="module")
-def emul():
+@pytest.fixture(scope="module", params=["libstenos_emul.so", "libstenos_emul_enc.so"], ids=["decode-shapes", "encode-shapes"])
+def emul(request):
+    """Both builds of tests/emul/Makefile: the shared copy helpers as the decode kernels and as the encoders compile them."""
     d = os.path.join(ROOT, "tests", "emul")
     subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
-    lib = ctypes.CDLL(os.path.join(d, "libstenos_emul.so"))
+    lib = ctypes.CDLL(os.path.join(d, request.param))
     lib.emul_block_compress.restype = c_size_t
     lib.emul_block_compress.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_int]
     lib.emul_block_decompress.restype = c_size_t
