@@ -60,13 +60,21 @@ STENOS_EXPORT size_t stenos_hip_unshuffle(const void* d_src, size_t bytesoftype,
 STENOS_EXPORT size_t stenos_hip_delta(const void* d_src, void* d_dst, size_t bytes, void* stream);
 STENOS_EXPORT size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t bytes, void* stream);
 
-/* Host-pointer calls on several devices.  stenos_set_threads(ctx, n) (stenos.h) says how many DEVICES -- PCIe links -- a
- * stenos_compress_generic / stenos_decompress_generic call with host pointers may use (the codec itself is an order of
- * magnitude faster than one link): from 64 MiB on, at level 0/1 with bytesoftype > 1, every device takes a contiguous
- * range of superblocks through a context and a host thread of its own, starting with the calling thread's current
- * device; frames are byte-identical to single-device frames.  The environment variable STENOS_HIP_DEVICES caps the
- * number.  This call returns how many devices the last host-pointer call on ctx used (1: the single-device path). */
+/* Host-pointer calls on several devices (the counterpart of the reference's thread dispatcher, stenos.cpp:909-1010,
+ * 1151-1202: a host-pointer call is bound by the PCIe link of its device, the codec is an order of magnitude faster).
+ * OPT-IN: by default a call stays on the calling thread's current device whatever stenos_set_threads() says -- that knob
+ * means CPU threads to an unmodified caller (stenos.h:140), and the other devices of a process are usually some other
+ * rank's.  After stenos_hip_set_devices(ctx, n >= 2) (or with STENOS_HIP_DEVICES >= 2 in the environment, read once, for
+ * callers that cannot be changed) a stenos_compress_generic / stenos_decompress_generic call of 64 MiB or more at level
+ * 0/1 with bytesoftype > 1 spreads over min(n, threads of stenos_set_threads, visible devices) devices, starting with the
+ * calling thread's current one: every device takes a contiguous range of superblocks through a context and a host thread
+ * of its own; frames are byte-identical to single-device frames.  n <= 1 turns it off again.
+ * stenos_hip_last_devices returns how many devices the last host-pointer call on ctx used (1: the single-device path). */
+STENOS_EXPORT void stenos_hip_set_devices(stenos_context* ctx, int devices);
 STENOS_EXPORT int stenos_hip_last_devices(stenos_context* ctx);
+/* Tests only: share_current_device != 0 lets the "devices" of such a call all stand for the current device (one-GPU
+ * boxes); fail_lane >= 0 keeps that lane from running, as if its device could not be made current (-1: none). */
+STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane);
 
 /* The fused encoder's waits for frame offsets are bounded; a launch that gives up (never observed) is redone without that
  * kernel instead of failing the call.  Returns how often that has happened on ctx.  inject > 0 (tests): the next

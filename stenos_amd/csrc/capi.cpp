@@ -241,6 +241,9 @@ struct stenos_context_s {
 	bool ev_valid[2] = { false, false };
 	hipStream_t up_stream = nullptr, main_stream = nullptr; // chunked host-pointer calls: uploads / coding + downloads
 	int last_devices = 1; // devices the last host-pointer call used
+	int hip_devices = 0;  // stenos_hip_set_devices: devices a host-pointer call may spread over (0: STENOS_HIP_DEVICES, else one)
+	bool test_lanes_share_device = false; // stenos_hip_test_lanes: the lanes all use the current device (one-GPU test boxes)
+	int test_fail_lane = -1;              // stenos_hip_test_lanes: this lane never runs (error-path test)
 	// what the last compression was asked to do: a fused launch that gave up waiting is done again without the fused kernel
 	const void* job_src = nullptr;
 	void* job_dst = nullptr;
@@ -1555,8 +1558,10 @@ void* device_alias(const void* p, size_t n)
 
 // ---- host-pointer calls on several devices ------------------------------------------------------------
 // The reference's dispatcher hands superblocks to the threads of stenos_set_threads (stenos.cpp:909-1010, 1151-1202).
-// Here a host-pointer call is bound by the PCIe link of the device, not by the codec, so the same knob says how many
-// DEVICES -- how many links -- a call may use: superblocks are independent in both directions, every device takes a
+// Here a host-pointer call is bound by the PCIe link of the device, not by the codec, so what pays is more DEVICES --
+// more links -- per call.  That is opt-in (stenos_hip_set_devices, or STENOS_HIP_DEVICES >= 2 in the environment): the
+// devices of a process are not the caller's to take just because it asked for CPU threads.  With it, a call uses
+// min(threads, devices) of them: superblocks are independent in both directions, every device takes a
 // contiguous range of them through a child context driven by a host thread of its own, and nothing is exchanged between
 // devices (no collective: the caller's buffers are the meeting point).
 //   compress:   every device uploads and encodes its range (a frame of its own, roomy destination); the sizes meet on
@@ -1565,42 +1570,42 @@ void* device_alias(const void* p, size_t n)
 //               last one or two of a frame -- or all of them under a tight dst_size -- follow on the calling thread's
 //               device with the exact room, as in the single-device path.
 //   decompress: the host walks the superblock headers anyway; every device gets a range of them and writes its bytes.
-// STENOS_HIP_DEVICES=n caps the devices used; STENOS_HIP_LANES_ON_ONE_DEVICE=1 (tests on a one-GPU box) lets the lanes
-// share the current device.
+// stenos_hip_test_lanes (tests on a one-GPU box) lets the lanes share the current device and makes one of them fail.
 constexpr size_t kLanesFrom = (size_t)64 << 20; // below, one link moves the data before a second thread is up
 
+// devices visible to the process (asked once: the answer does not change while the process lives)
+int visible_devices()
+{
+	static const int n = [] {
+		int k = 0;
+		return hipGetDeviceCount(&k) == hipSuccess && k > 0 ? k : 1;
+	}();
+	return n;
+}
+// How many devices a host-pointer call of `bytes` may spread over.  Opt-in: stenos_hip_set_devices(ctx, n >= 2), or the
+// environment variable STENOS_HIP_DEVICES >= 2 (read once) for callers that cannot be changed; without either a call stays
+// on the calling thread's device whatever stenos_set_threads() says (the reference's CPU-thread knob, stenos.h:140).
 int lane_count(stenos_context_s* ctx, size_t bytes)
 {
 	if (ctx->threads <= 1 || bytes < kLanesFrom)
 		return 1;
-	static const int cap = [] {
+	static const int env = [] {
 		const char* e = getenv("STENOS_HIP_DEVICES");
 		return e ? atoi(e) : 0;
 	}();
-	static const bool one = [] {
-		const char* e = getenv("STENOS_HIP_LANES_ON_ONE_DEVICE");
-		return e && e[0] == '1';
-	}();
-	int n = 0;
-	if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+	int n = ctx->hip_devices > 0 ? ctx->hip_devices : env;
+	if (n < 2)
 		return 1;
-	if (one)
-		n = 8;
-	if (cap > 0 && n > cap)
-		n = cap;
+	if (!ctx->test_lanes_share_device && n > visible_devices())
+		n = visible_devices();
 	return n < ctx->threads ? n : ctx->threads;
 }
 // lane 0 is the context itself (the calling thread's device); lane i > 0 a child on device (current + i) % count
 stenos_context_s* lane_context(stenos_context_s* ctx, int i, int* device)
 {
-	static const bool one = [] {
-		const char* e = getenv("STENOS_HIP_LANES_ON_ONE_DEVICE");
-		return e && e[0] == '1';
-	}();
-	int cur = 0, n = 1;
+	int cur = 0;
 	(void)hipGetDevice(&cur);
-	(void)hipGetDeviceCount(&n);
-	*device = one ? cur : (cur + i) % (n > 0 ? n : 1);
+	*device = ctx->test_lanes_share_device ? cur : (cur + i) % visible_devices();
 	if (i == 0)
 		return ctx;
 	if ((int)ctx->lanes.size() < i)
@@ -1618,15 +1623,18 @@ stenos_context_s* lane_context(stenos_context_s* ctx, int i, int* device)
 	l->custom_shift = ctx->custom_shift;
 	return l;
 }
-// runs fn(i) for every lane on a thread of its own (lane 0 on the calling thread) with the lane's device current
-bool run_lanes(int n, const std::vector<int>& device, const std::function<void(int)>& fn)
+// Runs fn(i) for every lane on a thread of its own (lane 0 on the calling thread) with the lane's device current.
+// result[i] must hold an error code on entry: a lane whose thread cannot be started, whose device cannot be made current
+// or that is made to fail by the test hook leaves it there, so a lane that never ran is an error, not a result of 0.
+bool run_lanes(stenos_context_s* ctx, int n, const std::vector<int>& device, const std::function<void(int)>& fn)
 {
 	std::vector<std::thread> th;
 	bool ok = true;
+	const int fail = ctx->test_fail_lane;
 	for (int i = 1; i < n; ++i) {
 		try {
 			th.emplace_back([&, i] {
-				if (hipSetDevice(device[(size_t)i]) == hipSuccess)
+				if (i != fail && hipSetDevice(device[(size_t)i]) == hipSuccess)
 					fn(i);
 			});
 		}
@@ -1635,7 +1643,7 @@ bool run_lanes(int n, const std::vector<int>& device, const std::function<void(i
 			break;
 		}
 	}
-	if (ok)
+	if (ok && fail != 0)
 		fn(0);
 	for (std::thread& t : th)
 		t.join();
@@ -1655,13 +1663,13 @@ size_t compress_lanes(stenos_context_s* ctx, const uint8_t* src, size_t T, size_
 	for (int i = 0; i < n; ++i)
 		if (!(lane[(size_t)i] = lane_context(ctx, i, &device[(size_t)i])))
 			return STENOS_ERROR_ALLOC;
-	std::vector<size_t> got((size_t)n, 0);
+	std::vector<size_t> got((size_t)n, (size_t)STENOS_ERROR_UNDEFINED); // (a lane that never runs is an error)
 	auto range = [&](int i, uint64_t* a, uint64_t* b) {
 		*a = safe * (uint64_t)i / (uint64_t)n;
 		*b = safe * (uint64_t)(i + 1) / (uint64_t)n;
 	};
 	// upload + encode
-	if (!run_lanes(n, device, [&](int i) {
+	if (!run_lanes(ctx, n, device, [&](int i) {
 		    stenos_context_s* c = lane[(size_t)i];
 		    uint64_t a, b;
 		    range(i, &a, &b);
@@ -1682,18 +1690,21 @@ size_t compress_lanes(stenos_context_s* ctx, const uint8_t* src, size_t T, size_
 	for (int i = 0; i < n; ++i) {
 		if (is_err(got[(size_t)i]))
 			return got[(size_t)i];
+		if (got[(size_t)i] < f.header)
+			return STENOS_ERROR_UNDEFINED;
 		off[(size_t)i + 1] = off[(size_t)i] + got[(size_t)i] - f.header;
 	}
 	if (off[(size_t)n] > dst_size)
 		return STENOS_ERROR_DST_OVERFLOW; // (cannot happen for safe superblocks; never write past the buffer)
 	// download, every range to its place
-	std::vector<int> bad((size_t)n, 0);
-	run_lanes(n, device, [&](int i) {
-		stenos_context_s* c = lane[(size_t)i];
-		if (hipMemcpyAsync(out + off[(size_t)i], c->out.as<uint8_t>() + f.header, got[(size_t)i] - f.header, hipMemcpyDeviceToHost, c->main_stream) != hipSuccess ||
-		    hipStreamSynchronize(c->main_stream) != hipSuccess)
-			bad[(size_t)i] = 1;
-	});
+	std::vector<int> bad((size_t)n, 1); // (cleared by the lane once its bytes are in place)
+	if (!run_lanes(ctx, n, device, [&](int i) {
+		    stenos_context_s* c = lane[(size_t)i];
+		    if (hipMemcpyAsync(out + off[(size_t)i], c->out.as<uint8_t>() + f.header, got[(size_t)i] - f.header, hipMemcpyDeviceToHost, c->main_stream) == hipSuccess &&
+			hipStreamSynchronize(c->main_stream) == hipSuccess)
+			    bad[(size_t)i] = 0;
+	    }))
+		return STENOS_ERROR_ALLOC;
 	for (int b : bad)
 		if (b)
 			return STENOS_ERROR_UNDEFINED;
@@ -1726,8 +1737,8 @@ size_t decompress_lanes(stenos_context_s* ctx, const uint8_t* in, size_t T, cons
 	for (int i = 0; i < n; ++i)
 		if (!(lane[(size_t)i] = lane_context(ctx, i, &device[(size_t)i])))
 			return STENOS_ERROR_ALLOC;
-	std::vector<size_t> got((size_t)n, 0);
-	if (!run_lanes(n, device, [&](int i) {
+	std::vector<size_t> got((size_t)n, (size_t)STENOS_ERROR_UNDEFINED); // (a lane that never runs is an error)
+	if (!run_lanes(ctx, n, device, [&](int i) {
 		    const uint64_t a = fi.nsb * (uint64_t)i / (uint64_t)n, b = fi.nsb * (uint64_t)(i + 1) / (uint64_t)n;
 		    stenos_context_s* c = lane[(size_t)i];
 		    got[(size_t)i] = !c->device_ready() ? (size_t)STENOS_ERROR_INVALID_INSTRUCTION_SET : (a < b ? decompress_chunked(c, in, T, fi, h_index, out, a, b) : 0);
@@ -2309,6 +2320,18 @@ size_t stenos_private_create_compression_header(size_t decompressed_size, size_t
 // =====================================================================================================
 
 int stenos_hip_last_devices(stenos_context* ctx) { return ctx ? ctx->last_devices : 0; }
+void stenos_hip_set_devices(stenos_context* ctx, int devices)
+{
+	if (ctx)
+		ctx->hip_devices = devices > 0 ? devices : 0;
+}
+void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane)
+{
+	if (!ctx)
+		return;
+	ctx->test_lanes_share_device = share_current_device != 0;
+	ctx->test_fail_lane = fail_lane;
+}
 int stenos_hip_fused_fallbacks(stenos_context* ctx, int inject)
 {
 	if (!ctx)

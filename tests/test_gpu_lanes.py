@@ -1,12 +1,9 @@
-"""Host-pointer calls on several devices (capi.cpp, compress_lanes / decompress_lanes): stenos_set_threads(ctx, n) lets a
-call use up to n devices, each taking a contiguous range of superblocks through a child context on a host thread of its
-own (reference dispatcher: stenos.cpp:909-1010, 1151-1202).  The test box has ONE GPU, so the lanes share it
-(STENOS_HIP_LANES_ON_ONE_DEVICE=1): what is checked is the orchestration -- the frame must be byte-identical to the
-single-device frame (roomy and tight destinations), and both decode paths must give the input back."""
-import os
-
-os.environ["STENOS_HIP_LANES_ON_ONE_DEVICE"] = "1"  # read once, at the first call with more than one thread
-
+"""Host-pointer calls on several devices (capi.cpp, compress_lanes / decompress_lanes): after stenos_hip_set_devices(ctx, n)
+a call with stenos_set_threads(ctx, n) uses up to n devices, each taking a contiguous range of superblocks through a child
+context on a host thread of its own (reference dispatcher: stenos.cpp:909-1010, 1151-1202).  The test box has ONE GPU, so
+the lanes share it (stenos_hip_test_lanes): what is checked is the orchestration -- the frame must be byte-identical to
+the single-device frame (roomy and tight destinations), both decode paths must give the input back, a lane that fails
+makes the call fail, and without the opt-in stenos_set_threads() leaves a call on one device."""
 import numpy as np
 import pytest
 
@@ -23,10 +20,18 @@ def lib():
     return load_library()
 
 
-def _compress(lib, data, T, threads, dst_size=None, level=1, expect_lanes=None):
+def _context(lib, threads, level=1, opt_in=True, fail_lane=-1):
     c = lib.stenos_make_context()
     lib.stenos_set_level(c, level)
     lib.stenos_set_threads(c, threads)
+    if opt_in:
+        lib.stenos_hip_set_devices(c, threads)
+    lib.stenos_hip_test_lanes(c, 1, fail_lane)
+    return c
+
+
+def _compress(lib, data, T, threads, dst_size=None, level=1, expect_lanes=None):
+    c = _context(lib, threads, level)
     cap = lib.stenos_bound(data.nbytes) if dst_size is None else dst_size
     out = np.full(cap + 64, 0x5A, dtype=np.uint8)
     r = lib.stenos_compress_generic(c, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
@@ -49,8 +54,7 @@ def test_lanes_frame_equals_single_device_frame(lib, kind, T, mib, threads):
     assert np.array_equal(fn, f1)
     # decode on lanes and on one device
     for th in (threads, 1):
-        c = lib.stenos_make_context()
-        lib.stenos_set_threads(c, th)
+        c = _context(lib, th)
         back = np.full(data.nbytes + 64, 0x5A, dtype=np.uint8)
         assert lib.stenos_decompress_generic(c, np_ptr(fn), T, rn, np_ptr(back), data.nbytes) == data.nbytes
         assert lib.stenos_hip_last_devices(c) == (1 if kind == "rand" else th)  # (a frame of copies is decoded by the host: no device at all)
@@ -79,3 +83,44 @@ def test_lanes_incompressible_input_at_the_bound(lib):
     r1, f1 = _compress(lib, data, T, 1)
     r3, f3 = _compress(lib, data, T, 3, expect_lanes=3)
     assert not has_error(r1) and r1 == r3 and np.array_equal(f1, f3)
+
+
+def test_threads_alone_stay_on_one_device(lib):
+    """stenos_set_threads(ctx, 64) from an unmodified caller means CPU threads: without stenos_hip_set_devices (or
+    STENOS_HIP_DEVICES) the call does not spread over devices."""
+    T = 4
+    data = generate("rand12", T, (80 << 20) // T + 5, 3)
+    c = _context(lib, 64, opt_in=False)
+    cap = lib.stenos_bound(data.nbytes)
+    out = np.zeros(cap, dtype=np.uint8)
+    r = lib.stenos_compress_generic(c, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
+    assert not has_error(r) and lib.stenos_hip_last_devices(c) == 1
+    back = np.zeros(data.nbytes, dtype=np.uint8)
+    assert lib.stenos_decompress_generic(c, np_ptr(out), T, r, np_ptr(back), data.nbytes) == data.nbytes
+    assert lib.stenos_hip_last_devices(c) == 1
+    lib.stenos_destroy_context(c)
+    assert np.array_equal(back, data.view(np.uint8).ravel())
+
+
+@pytest.mark.parametrize("fail_lane", [0, 1, 2])
+def test_a_failing_lane_fails_the_call(lib, fail_lane):
+    """A lane that never runs (its device cannot be made current, its thread cannot start) must end in an error code:
+    no frame with a hole in it, no output with a range that was never decoded."""
+    T = 4
+    data = generate("rand12", T, (96 << 20) // T + 77, 5)
+    r1, f1 = _compress(lib, data, T, 1)
+    c = _context(lib, 3, fail_lane=fail_lane)
+    cap = lib.stenos_bound(data.nbytes)
+    out = np.zeros(cap, dtype=np.uint8)
+    r = lib.stenos_compress_generic(c, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
+    assert has_error(r), hex(r)
+    back = np.zeros(data.nbytes, dtype=np.uint8)
+    r = lib.stenos_decompress_generic(c, np_ptr(f1), T, r1, np_ptr(back), data.nbytes)
+    assert has_error(r), hex(r)
+    # the same context works again once the lane does
+    lib.stenos_hip_test_lanes(c, 1, -1)
+    r = lib.stenos_compress_generic(c, np_ptr(data), T, data.nbytes, np_ptr(out), cap)
+    assert r == r1 and np.array_equal(out[:r], f1)
+    assert lib.stenos_decompress_generic(c, np_ptr(f1), T, r1, np_ptr(back), data.nbytes) == data.nbytes
+    assert np.array_equal(back, data.view(np.uint8).ravel())
+    lib.stenos_destroy_context(c)
