@@ -4,7 +4,8 @@
 Metric (BASELINE.json): encode+decode GB/s of input bytes at level 1 on int32, with the compression
 ratio.  One "step" = one level-1 encode pass + one decode pass over the synthetic typed array that is
 already resident in HBM (device-pointer entry points of libstenos.so; nothing crosses PCIe except the
-8-byte frame size).  value = input bytes of all ranks / (encode + decode time).
+8-byte frame size).  The decoder is handed the frame and nothing else (no index from the encoder: the superblock
+chain is walked on the device inside the timed region).  value = input bytes of all ranks / (encode + decode time).
 
 Workload at N=1: BASELINE.json configs[1], 8 GiB int32 (2^31 elements, bytesoftype 4, level 1 block
 codec only), variant (b) of SURVEY.md section 8d: uniform 12-bit values `u & 0xFFF` from splitmix64 seed 42
@@ -130,8 +131,11 @@ def run_workload(st, torch, src, T, steps, warmup, dist, world, blocking=False):
         st.compress(src, T, dst, wait=False)
         return st.finish()  # the frame size is a host value the decoder needs
 
-    def dec(csize):
-        idx, nsb = st.last_index()
+    def dec(csize, indexed=False):
+        # The decoder gets the FRAME and nothing else: the superblock chain is found on the device (csrc/walk.h) inside the
+        # timed region.  indexed=True (an extra leg behind the timed region) hands over the index the encoder left behind,
+        # which a decoder in the same process could use.
+        idx, nsb = st.last_index() if indexed else (None, 0)
         if blocking:
             st.decompress(dst, T, csize, back, index_ptr=idx if nsb else None)
         else:
@@ -172,7 +176,16 @@ def run_workload(st, torch, src, T, steps, warmup, dist, world, blocking=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     ok = bool(torch.equal(back, src))
-    return dict(wall=wall, enc_s=enc_s, dec_s=dec_s, kenc_ms=kenc / max(steps, 1), kdec_ms=kdec / max(steps, 1), csize=csize, ok=ok)
+    # extra leg, outside the timed region: the same decode with the encoder's index handed over (no walk)
+    back.zero_()
+    ev[0].record()
+    for _ in range(steps):
+        dec(csize, indexed=True)
+    ev[1].record()
+    ev[1].synchronize()
+    dec_indexed_s = ev[0].elapsed_time(ev[1]) / 1e3
+    ok = ok and bool(torch.equal(back, src))
+    return dict(wall=wall, enc_s=enc_s, dec_s=dec_s, dec_indexed_s=dec_indexed_s, kenc_ms=kenc / max(steps, 1), kdec_ms=kdec / max(steps, 1), csize=csize, ok=ok)
 
 
 CONFIGS = {
@@ -211,7 +224,8 @@ def measure_other(name, torch, dist, dev, with_cpu):
     assert r["ok"], name
     nb = src.numel()
     e = {"workload": desc, "bytesoftype": T, "level": level, "value": round(nb * steps / r["wall"] / 1e9, 3), "unit": "GB/s", "steps": steps,
-         "compression_ratio": round(nb / r["csize"], 4), "encode_gbps": round(nb * steps / r["enc_s"] / 1e9, 3), "decode_gbps": round(nb * steps / r["dec_s"] / 1e9, 3)}
+         "compression_ratio": round(nb / r["csize"], 4), "encode_gbps": round(nb * steps / r["enc_s"] / 1e9, 3), "decode_gbps": round(nb * steps / r["dec_s"] / 1e9, 3),
+         "decode_indexed_gbps": round(nb * steps / r["dec_indexed_s"] / 1e9, 3), "decode_input": "the frame alone (header chain walked on the device inside the timed region)"}
     if level == 1 and T > 1:
         algo = nb + r["csize"]
         roof = roofline("encode_superblocks", algo, r["kenc_ms"])
@@ -411,6 +425,10 @@ def main():
             "compression_ratio": round(ratio, 4),
             "encode_gbps": round(nbytes * args.steps / r["enc_s"] / 1e9, 3),
             "decode_gbps": round(nbytes * args.steps / r["dec_s"] / 1e9, 3),
+            "decode_input": "the frame alone: the superblock chain is walked on the device inside the timed region (csrc/walk.h); decode_indexed_gbps is the "
+                            "same decode with the encoder's index handed over (a decoder in the encoder's process), measured behind the timed region",
+            "decode_indexed_gbps": round(nbytes * args.steps / r["dec_indexed_s"] / 1e9, 3),
+            "value_with_indexed_decode": round(nbytes * args.steps / (r["enc_s"] + r["dec_indexed_s"]) / 1e9, 3),
             "roofline": roof,
         }
     # the literal "random int32" variant: every superblock becomes COPY (reported next to the headline, with its own roofline)
@@ -424,7 +442,8 @@ def main():
         roof2["decode_superblocks"] = {kk: v for kk, v in roofline("decode_superblocks", algo2, r2["kdec_ms"]).items() if kk in ("achieved", "frac", "kernel_ms")}
         out["full_entropy"] = {"workload": "the literal configs[1]: uniform 32-bit values (splitmix64 seed 42), every superblock stored as a copy",
                                "value": round(nbytes * k / r2["wall"] / 1e9, 3), "compression_ratio": round(nbytes / r2["csize"], 5),
-                               "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3), "roofline": roof2}
+                               "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3),
+                               "decode_indexed_gbps": round(nbytes * k / r2["dec_indexed_s"] / 1e9, 3), "roofline": roof2}
         del src2
     if world == 1 and not args.no_cpu_baseline:
         mib = min(args.cpu_sample_mib, nbytes >> 20)

@@ -39,14 +39,15 @@ STENOS_EXPORT size_t stenos_hip_finish(stenos_context* ctx);
 STENOS_EXPORT const uint64_t* stenos_hip_last_index(stenos_context* ctx, size_t* nsb);
 
 /* Superblock index of any frame held in device memory: the chain of [code][csize:3] headers (reference
- * stenos.cpp:1126-1134, 1166-1182) is walked on the device.  Returns a device array of *nsb + 1 uint64 byte offsets
+ * stenos.cpp:1126-1134, 1166-1182) is walked on the device -- by segments of the frame in parallel, with a result that is
+ * proven equal to the serial walk's before it is used (csrc/walk.h).  Returns a device array of *nsb + 1 uint64 byte offsets
  * (the last entry is the end of the last superblock), valid until the next call on ctx; NULL for an empty,
  * malformed or truncated frame.  Waits for the walk.  What a multi-GPU decoder cuts the frame with. */
 STENOS_EXPORT const uint64_t* stenos_hip_frame_index(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, size_t* nsb, void* stream);
 
 /* Decompress a frame held in device memory.  d_index may be NULL: the superblock chain
- * ([code][csize:3] headers, reference stenos.cpp:1129-1134) is then walked on the device first
- * (serial, latency bound); passing the index produced by stenos_hip_last_index() skips that walk.
+ * ([code][csize:3] headers, reference stenos.cpp:1129-1134) is then walked on the device first (in parallel,
+ * csrc/walk.h: tens of microseconds); passing the index produced by stenos_hip_last_index() skips that walk.
  * Returns the decompressed size or an error code. */
 STENOS_EXPORT size_t stenos_hip_decompress(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
 STENOS_EXPORT size_t stenos_hip_decompress_async(stenos_context* ctx, const void* d_src, size_t bytesoftype, size_t bytes, void* d_dst, size_t dst_size, const uint64_t* d_index, void* stream);
@@ -75,6 +76,10 @@ STENOS_EXPORT int stenos_hip_last_devices(stenos_context* ctx);
 /* Tests only: share_current_device != 0 lets the "devices" of such a call all stand for the current device (one-GPU
  * boxes); fail_lane >= 0 keeps that lane from running, as if its device could not be made current (-1: none). */
 STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane);
+
+/* Tests only: serial != 0 makes frames that come without an index be walked by one lane (the serial walk that the
+ * parallel one of walk.h is proven against, and falls back to). */
+STENOS_EXPORT void stenos_hip_test_walk(stenos_context* ctx, int serial);
 
 /* The fused encoder's waits for frame offsets are bounded; a launch that gives up (never observed) is redone without that
  * kernel instead of failing the call.  Returns how often that has happened on ctx.  inject > 0 (tests): the next

@@ -225,6 +225,8 @@ struct stenos_context_s {
 	DevBuf chain;                                    // fused path: ticket counter + one chained-scan word per superblock
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
+	DevBuf walk;                                     // segments of the parallel header walk (walk.h)
+	bool test_serial_walk = false;                   // stenos_hip_test_walk: frames without an index are walked by one lane
 	DevBuf wide;                                     // bytesoftype above 64: scratch of the HBM-resident kernels (kernels_wide.hip)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) unused, [24,32) scan carry, [64,320) override payload
 	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage; // host staging of the strategy layer
@@ -258,7 +260,7 @@ struct stenos_context_s {
 
 	void release_device_state()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide, &walk };
 		for (DevBuf* b : all)
 			b->release();
 		if (h_total)
@@ -302,7 +304,7 @@ struct stenos_context_s {
 				l->~stenos_context_s();
 				free(l);
 			}
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide, &walk };
 		for (DevBuf* b : all)
 			b->release();
 		HostBuf* host[] = { &h_in, &h_out, &h_blocks, &h_shuf, &h_mid0, &h_mid1, &h_stage };
@@ -1322,7 +1324,10 @@ size_t decompress_device(stenos_context_s* ctx, const void* d_src, size_t T, siz
 		return STENOS_ERROR_UNDEFINED;
 	if (!d_index) {
 		d_index = ctx->sboff.as<uint64_t>();
-		if (stenos_k_launch_walk((const uint8_t*)d_src, size, fi.header, fi.nsb, ctx->sboff.as<uint64_t>(), d_status, stream) != hipSuccess)
+		if (!ctx->walk.ensure(stenos_k_walk_scratch_bytes()))
+			return STENOS_ERROR_ALLOC;
+		if (stenos_k_launch_walk((const uint8_t*)d_src, size, fi.header, fi.nsb, (uint32_t)fi.sb, ctx->sboff.as<uint64_t>(), d_status,
+					 ctx->test_serial_walk ? nullptr : ctx->walk.p, stream) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
 	}
 	DecodeArgs a;
@@ -2325,6 +2330,11 @@ void stenos_hip_set_devices(stenos_context* ctx, int devices)
 	if (ctx)
 		ctx->hip_devices = devices > 0 ? devices : 0;
 }
+void stenos_hip_test_walk(stenos_context* ctx, int serial)
+{
+	if (ctx)
+		ctx->test_serial_walk = serial != 0;
+}
 void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane)
 {
 	if (!ctx)
@@ -2488,12 +2498,13 @@ const uint64_t* stenos_hip_frame_index(stenos_context* ctx, const void* d_src, s
 	FrameInfo fi;
 	if (is_err(parse_frame(h, have, bytesoftype, ~(size_t)0, fi)) || fi.total == 0)
 		return nullptr;
-	if (!ctx->misc.ensure(4096) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
+	if (!ctx->misc.ensure(4096) || !ctx->sboff.ensure((fi.nsb + 2) * 8) || !ctx->walk.ensure(stenos_k_walk_scratch_bytes()))
 		return nullptr;
 	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
 	uint32_t status = 0;
 	if (hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess ||
-	    stenos_k_launch_walk((const uint8_t*)d_src, bytes, fi.header, fi.nsb, ctx->sboff.as<uint64_t>(), d_status, stream) != hipSuccess ||
+	    stenos_k_launch_walk((const uint8_t*)d_src, bytes, fi.header, fi.nsb, (uint32_t)fi.sb, ctx->sboff.as<uint64_t>(), d_status,
+				 ctx->test_serial_walk ? nullptr : ctx->walk.p, stream) != hipSuccess ||
 	    hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || status)
 		return nullptr; // a header or payload runs past the end of the frame
 	if (nsb)

@@ -1,5 +1,5 @@
 // decode_kernels.hip -- gfx950 kernels of the decode pipeline and their launchers.
-//   walk_superblocks   (only without an index) serial walk of the [code][csize:3] chain (stenos.cpp:1129-1134)
+//   (the [code][csize:3] chain of a frame that comes without an index is walked by walk_kernels.hip)
 //   decode_superblocks one wavefront per superblock (block_compress.h:2088-2175)
 //
 // A translation unit of its own because it is compiled with -mllvm -structurizecfg-skip-uniform-regions (csrc/Makefile):
@@ -19,28 +19,6 @@ using namespace wv;
 namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
-
-// Serial walk of the superblock chain by one lane: off[s] = byte offset of superblock s's header.
-__global__ void walk_superblocks(const uint8_t* __restrict__ frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* __restrict__ off,
-				 uint32_t* __restrict__ status)
-{
-	if (threadIdx.x != 0 || blockIdx.x != 0)
-		return;
-	uint64_t p = first;
-	for (uint64_t s = 0; s < nsb; ++s) {
-		if (p + 4 > size) { // stenos.cpp:1126-1127
-			atomicOr(status, DECODE_STATUS_TRUNCATED);
-			for (; s <= nsb; ++s) off[s] = size;
-			return;
-		}
-		off[s] = p;
-		uint32_t csize = (uint32_t)frame[p + 1] | ((uint32_t)frame[p + 2] << 8) | ((uint32_t)frame[p + 3] << 16);
-		p += 4 + (uint64_t)csize;
-	}
-	off[nsb] = p;
-	if (p > size)
-		atomicOr(status, DECODE_STATUS_TRUNCATED);
-}
 
 template <uint32_t TT>
 __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
@@ -85,12 +63,6 @@ __global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
 }
 
 } // namespace
-
-hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream)
-{
-	hipLaunchKernelGGL(walk_superblocks, dim3(1), dim3(64), 0, stream, frame, size, first, nsb, off, status);
-	return hipGetLastError();
-}
 
 template <uint32_t TT>
 static hipError_t launch_decode_t(const DecodeArgs& a, hipStream_t stream)

@@ -38,7 +38,11 @@ hipError_t stenos_k_launch_scan(const codec::FrameJob& j, uint64_t s_begin, uint
 hipError_t stenos_k_launch_resolve(const codec::FrameJob& j, hipStream_t stream);
 hipError_t stenos_k_launch_keep_superblocks(const uint8_t* keep, uint8_t* code, uint32_t* csize, uint64_t nsb, hipStream_t stream);
 hipError_t stenos_k_launch_pack(const codec::FrameJob& j, uint64_t s_begin, uint64_t s_end, hipStream_t stream);
-hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint64_t* off, uint32_t* status, hipStream_t stream);
+// walk_kernels.hip: off[0 .. nsb] of a frame without an index.  scratch: stenos_k_walk_scratch_bytes() of device memory for
+// the parallel walk (walk.h); NULL: the serial walk by one lane.
+hipError_t stenos_k_launch_walk(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint32_t sb_bytes, uint64_t* off, uint32_t* status, void* scratch,
+				hipStream_t stream);
+size_t stenos_k_walk_scratch_bytes();
 hipError_t stenos_k_launch_decode(const DecodeArgs& a, hipStream_t stream);
 
 // kernels_wide.hip: bytesoftype above codec::MAX_T of the LDS-resident kernels (the launchers above forward to these)

@@ -4,9 +4,11 @@
 // The shipped library never contains or calls this.
 #define WV_HOST_EMULATION 1
 #include "../../stenos_amd/csrc/pipeline.h"
+#include "../../stenos_amd/csrc/walk.h"
 
 #include <dlfcn.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <vector>
@@ -285,4 +287,82 @@ void emul_copy_g2g_wide(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g_w
 
 size_t emul_lds_bytes_encode(size_t T) { return make_layout((uint32_t)T, true).total; }
 size_t emul_lds_bytes_decode(size_t T) { return make_dec_layout((uint32_t)T).total; }
+
+// ---- walk.h: the parallel header walk, its kernels replayed lane by lane (walk_kernels.hip) --------------------------
+// off[0 .. nsb], *status |= 1 for a truncated chain as the serial walk says.  Returns the number of segments (0: the plan
+// chose the serial walk) or -1 when the speculation failed and the serial walk has to run.
+int emul_walk_parallel(const uint8_t* frame, uint64_t size, uint64_t first, uint64_t nsb, uint32_t sb_bytes, uint64_t seg_len, uint64_t* off, uint32_t* status)
+{
+	using namespace walk;
+	const Plan P = make_plan(first, size, nsb, sb_bytes, seg_len);
+	if (P.nseg == 0)
+		return 0;
+	std::vector<Segment> seg(P.nseg);
+	for (Segment& s : seg) {
+		memset(&s, 0xDB, sizeof s); // (stale contents of the device buffer)
+	}
+	struct Add {
+		uint32_t operator()(uint32_t* c) const { return (*c)++; }
+	};
+	for (uint32_t k = 0; k < P.nseg; ++k) { // walk_speculate
+		if (k == 0) {
+			follow_first(P, frame, &seg[0]);
+			continue;
+		}
+		if (k + 1 >= P.nseg)
+			continue;
+		uint64_t roots[LANES];
+		uint32_t nroots = 0;
+		const uint64_t begin = seg_begin(P, k), wend = begin + P.window;
+		for (uint32_t lane = 0; lane < LANES; ++lane)
+			for (uint64_t base = begin + lane * 16u; base < wend; base += LANES * 16u)
+				scan_window16(P, frame, k, base, roots, &nroots, Add());
+		uint32_t live = 0, hops[LANES];
+		uint64_t exit[LANES];
+		bool alive[LANES] = { false };
+		if (nroots <= LANES)
+			for (uint32_t lane = 0; lane < nroots; ++lane)
+				if ((alive[lane] = follow_root(P, frame, k, roots[lane], &exit[lane], &hops[lane])))
+					++live;
+		bool ok = live >= 1 && live <= MAX_ROOTS;
+		uint32_t lead = 0;
+		while (ok && !alive[lead])
+			++lead;
+		for (uint32_t lane = 0; ok && lane < LANES; ++lane)
+			if (alive[lane] && exit[lane] != exit[lead])
+				ok = false;
+		if (ok) {
+			uint32_t i = 0;
+			for (uint32_t lane = 0; lane < LANES; ++lane)
+				if (alive[lane]) {
+					seg[k].root[i] = roots[lane];
+					seg[k].hops[i] = hops[lane];
+					++i;
+				}
+			seg[k].exit = exit[lead];
+			seg[k].count = 0;
+			seg[k].nroots = live;
+			seg[k].state = SEG_OK;
+		}
+		else {
+			seg[k].state = SEG_UNRESOLVED;
+			if (getenv("WALK_DEBUG")) fprintf(stderr, "seg %u: %u roots, %u live\n", k, nroots, live);
+		}
+	}
+	bool failed = false;
+	for (uint32_t k = 0; k < P.nseg; ++k) // walk_verify (its lanes only read what walk_speculate wrote)
+		if (!verify_segment(P, frame, k, seg.data())) {
+			if (getenv("WALK_DEBUG")) fprintf(stderr, "verify %u failed: prev exit %llu root %llu begin %llu\n", k, (unsigned long long)seg[k-1].exit, (unsigned long long)seg[k].root[0], (unsigned long long)seg_begin(P,k));
+			failed = true;
+		}
+	if (failed)
+		return -1;
+	for (uint32_t k = 0; k < P.nseg; ++k) { // walk_write
+		uint64_t sum = 0;
+		for (uint32_t j = 0; j < k; ++j)
+			sum += seg[j].count;
+		*status |= write_segment(P, frame, k, seg.data(), sum, off, 1u);
+	}
+	return (int)P.nseg;
+}
 }

@@ -10,6 +10,6 @@ flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contr
 obj="$here/stenos_amd/lib/exp/decode_kernels_$name.o"
 hipcc $flags "$@" -mllvm -structurizecfg-skip-uniform-regions=1 -c "$src/decode_kernels.hip" -o "$obj" 2>/dev/null
 hipcc $flags ${ENCODE_FLAGS--DWV_PREDICATE_BRANCHES} "$@" -shared -Wl,-Bsymbolic \
-  "$obj" "$src/kernels.hip" "$src/kernels_wide.hip" "$src/byte_kernels.hip" "$src/capi.cpp" "$src/strategy.cpp" -o "$here/stenos_amd/lib/exp/libstenos_$name.so" -ldl 2>/dev/null
+  "$obj" "$src/kernels.hip" "$src/kernels_wide.hip" "$src/byte_kernels.hip" "$src/walk_kernels.hip" "$src/capi.cpp" "$src/strategy.cpp" -o "$here/stenos_amd/lib/exp/libstenos_$name.so" -ldl 2>/dev/null
 rm -f "$obj"
 echo "built libstenos_$name.so"

@@ -94,6 +94,46 @@ constexpr int UNROLL = 64; // instructions per loop trip (8 chains x 8)
 #define I_DSRDU8(r) asm volatile("ds_read_u8 %0, %1" : "=v"(r) : "v"(lab));
 #define I_DSWRB8(r) asm volatile("ds_write_b8 %1, %0" : : "v"(r), "v"(lab));
 
+// ---- round 4: operands from scalar registers, 16-bit forms, lane swaps, LDS widths -------------------------------------
+#define I_XORS(r) asm volatile("v_xor_b32 %0, s20, %0" : "+v"(r));
+#define I_ANDS(r) asm volatile("v_and_b32 %0, s20, %0" : "+v"(r));
+#define I_MOVS(r) asm volatile("v_mov_b32 %0, s20" : "=v"(r));
+#define I_MOVLIT(r) asm volatile("v_mov_b32 %0, 0x12345678" : "=v"(r));
+#define I_PERMS(r) asm volatile("v_perm_b32 %0, %0, %1, s20" : "+v"(r) : "v"(k));
+#define I_BITOP3(r) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8" : "+v"(r) : "v"(k), "v"(k2));
+#define I_PKMINSEL(r) asm volatile("v_pk_min_u16 %0, %0, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(r));
+#define I_PLSWAP(r) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r), "+v"(k));
+#define I_PL16SWAP(r) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r), "+v"(k));
+#define I_MINU16(r) asm volatile("v_min_u16 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_MAXU16(r) asm volatile("v_max_u16 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_SUBU16(r) asm volatile("v_sub_u16 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_LSHRB16(r) asm volatile("v_lshrrev_b16 %0, 1, %0" : "+v"(r));
+#define I_LSHLB16(r) asm volatile("v_lshlrev_b16 %0, 1, %0" : "+v"(r));
+#define I_LSHRV(r) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(r) : "v"(k));
+#define I_ASHR(r) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r));
+#define I_MINI32(r) asm volatile("v_min_i32 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_XAD(r) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(k2));
+#define I_LSHLOR(r) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(r) : "v"(k));
+#define I_OR3(r) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(k2));
+#define I_ADDF(r) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_MULF(r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_CVTUB(r) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(r));
+#define I_SUBREV(r) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(r) : "v"(k));
+#define I_ANDINL(r) asm volatile("v_and_b32 %0, 15, %0" : "+v"(r));
+#define I_DOT4(r) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(k2));
+#define I_MSAD(r) asm volatile("v_msad_u8 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(k2));
+#define I_SLOAD(r) asm volatile("s_load_dword s20, %0, 0x0\n s_waitcnt lgkmcnt(0)" : : "s"(cyc) : "s20");
+#define I_SLOADNW(r) asm volatile("s_load_dword s20, %0, 0x0" : : "s"(cyc) : "s20");
+#define I_DSWR64(r) asm volatile("ds_write_b64 %1, %0" : : "v"(r##w), "v"(la4));
+#define I_DSWR64U(r) asm volatile("ds_write_b64 %1, %0" : : "v"(r##w), "v"(lab));
+#define I_DSWR32U(r) asm volatile("ds_write_b32 %1, %0" : : "v"(r), "v"(lab));
+#define I_DSWR128U(r) asm volatile("ds_write_b128 %1, %0" : : "v"(q##r), "v"(lab));
+#define I_DSOR64(r) asm volatile("ds_or_b64 %1, %0" : : "v"(r##w), "v"(la4));
+#define I_DSWR16(r) asm volatile("ds_write_b16 %1, %0" : : "v"(r), "v"(lab));
+#define I_DSRD128U(r) asm volatile("ds_read_b128 %0, %1" : "=v"(q##r) : "v"(lab));
+#define I_DSWR2(r) asm volatile("ds_write2_b32 %1, %0, %0 offset0:1 offset1:65" : : "v"(r), "v"(la));
+#define I_DSWR2ST64(r) asm volatile("ds_write2st64_b32 %1, %0, %0 offset0:1 offset1:3" : : "v"(r), "v"(la));
+
 typedef uint32_t u32;
 typedef uint64_t u64;
 
@@ -190,6 +230,45 @@ BOTH(k_dsoru, I_DSORU)
 BOTH(k_dsrdu8, I_DSRDU8)
 BOTH(k_dswrb8, I_DSWRB8)
 
+BOTH(k_xors, I_XORS)
+BOTH(k_ands, I_ANDS)
+BOTH(k_movs, I_MOVS)
+BOTH(k_movlit, I_MOVLIT)
+BOTH(k_perms, I_PERMS)
+BOTH(k_bitop3, I_BITOP3)
+BOTH(k_pkminsel, I_PKMINSEL)
+BOTH(k_plswap, I_PLSWAP)
+BOTH(k_pl16swap, I_PL16SWAP)
+BOTH(k_minu16, I_MINU16)
+BOTH(k_maxu16, I_MAXU16)
+BOTH(k_subu16, I_SUBU16)
+BOTH(k_lshrb16, I_LSHRB16)
+BOTH(k_lshlb16, I_LSHLB16)
+BOTH(k_lshrv, I_LSHRV)
+BOTH(k_ashr, I_ASHR)
+BOTH(k_mini32, I_MINI32)
+BOTH(k_xad, I_XAD)
+BOTH(k_lshlor, I_LSHLOR)
+BOTH(k_or3, I_OR3)
+BOTH(k_addf, I_ADDF)
+BOTH(k_mulf, I_MULF)
+BOTH(k_cvtub, I_CVTUB)
+BOTH(k_subrev, I_SUBREV)
+BOTH(k_andinl, I_ANDINL)
+BOTH(k_dot4, I_DOT4)
+BOTH(k_msad, I_MSAD)
+BOTH(k_sload, I_SLOAD)
+BOTH(k_sloadnw, I_SLOADNW)
+BOTH(k_dswr64, I_DSWR64)
+BOTH(k_dswr64u, I_DSWR64U)
+BOTH(k_dswr32u, I_DSWR32U)
+BOTH(k_dswr128u, I_DSWR128U)
+BOTH(k_dsor64, I_DSOR64)
+BOTH(k_dswr16, I_DSWR16)
+BOTH(k_dsrd128u, I_DSRD128U)
+BOTH(k_dswr2, I_DSWR2)
+BOTH(k_dswr2st64, I_DSWR2ST64)
+
 struct Entry {
 	const char* name;
 	void (*ind)(u32*, int, u64*);
@@ -197,7 +276,7 @@ struct Entry {
 };
 #define E(N) { #N, N##_ind, N##_dep }
 
-int main()
+int main(int argc, char**)
 {
 	hipDeviceProp_t prop;
 	CHECK(hipGetDeviceProperties(&prop, 0));
@@ -213,11 +292,12 @@ int main()
 	std::vector<Entry> es = { E(k_add), E(k_and), E(k_lshl), E(k_andor), E(k_lshladd), E(k_add3), E(k_bfe), E(k_perm), E(k_pkmin), E(k_min),
 		E(k_min3), E(k_cndmask), E(k_bcnt), E(k_ffbh), E(k_mullo), E(k_mul24), E(k_mad24), E(k_dppq), E(k_dppadd), E(k_dppror), E(k_sdwa),
 		E(k_sadu8), E(k_cmp), E(k_cmps), E(k_readlane), E(k_fma), E(k_pkfma), E(k_salu), E(k_bperm), E(k_bpermnw), E(k_or), E(k_sub), E(k_lshr), E(k_lshlv), E(k_max), E(k_mov), E(k_not), E(k_bfi), E(k_alignbit), E(k_addlit), E(k_andlit), E(k_adds), E(k_addco), E(k_adde64), E(k_xore64), E(k_cndvcc), E(k_cnds), E(k_cmpcnd), E(k_addcnd), E(k_mbcnt), E(k_pkadd), E(k_pksub), E(k_pklshl), E(k_addu16), E(k_sdwaadd), E(k_sdwadst), E(k_dsrd32), E(k_dsrd64), E(k_dsrd128), E(k_dswr32), E(k_dswr128), E(k_dsor), E(k_dsoru), E(k_dsrdu8), E(k_dswrb8) };
+	if (argc > 1) es = { E(k_xors), E(k_ands), E(k_movs), E(k_movlit), E(k_perms), E(k_bitop3), E(k_pkminsel), E(k_plswap), E(k_pl16swap), E(k_minu16), E(k_maxu16), E(k_subu16), E(k_lshrb16), E(k_lshlb16), E(k_lshrv), E(k_ashr), E(k_mini32), E(k_xad), E(k_lshlor), E(k_or3), E(k_addf), E(k_mulf), E(k_cvtub), E(k_subrev), E(k_andinl), E(k_dot4), E(k_msad), E(k_sload), E(k_sloadnw), E(k_dswr64), E(k_dswr64u), E(k_dswr32u), E(k_dswr128u), E(k_dsor64), E(k_dswr16), E(k_dsrd128u), E(k_dswr2), E(k_dswr2st64) };
 	const int trips = 2000;
 	printf("cycles per wave-instruction per SIMD (shader clock from s_memtime of one wave / wall clock of the grid)\n");
 	printf("%-12s %5s | %9s %9s | %9s %9s\n", "instr", "w/SIMD", "ind own", "ind simd", "dep own", "dep simd");
 	for (auto& e : es) {
-		for (int wps : { 1, 2, 4, 8 }) {
+		for (int wps : { 1, 8 }) {
 			// blocks of 256 threads = 4 waves = one per SIMD; wps blocks per CU
 			double r[4];
 			for (int d = 0; d < 2; ++d) {
