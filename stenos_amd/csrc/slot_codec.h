@@ -15,6 +15,15 @@
 
 namespace codec {
 
+#include "shape_tables.inc" // SHAPE_LANES_T4 / _T2, SHAPE_INFO_T4 / _T2 (tools/gen_shape_tables.py)
+
+// What lane 16*s + r has to know about a pass of shape act0 | act1 << 4 (fields: tools/gen_shape_tables.py).
+WV_FN U32 shape_lane_entry(uint32_t T, uint32_t shape)
+{
+	const uint8_t* t = (const uint8_t*)(T == 2 ? SHAPE_LANES_T2 : SHAPE_LANES_T4);
+	return gld32(t + shape * 256u, lane_id() * 4u, pred_all(true));
+}
+
 constexpr uint32_t SLOT2_BYTES = 256; // lane 16*s + r reads LDS bytes [16*lane, 16*lane + 16) of the slot area: no bank conflicts
 WV_HD uint32_t slot2_area(const Layout& L) { return L.aux; }
 
@@ -261,26 +270,19 @@ struct SlotBatch {
 	uint32_t full[2];  // sum of the plane sizes of each block (block_compress.h:1189-1207)
 };
 
-// Where the planes go: P.pbase = offset of the slot's plane in its block's encoding, P.k its plane number, P.blk its block.
+// Where the planes go: P.pbase = offset of the slot's plane in its block's encoding; P.e: the lane's entry of the shape table
+// (plane number, block, SAME planes around the plane); P.first: first element of the slot's block.
 struct SlotPlace {
-	U32 pbase, k, blk, act, first;
-	Pred valid;
+	U32 pbase, e, first;
+	Pred valid, second;
 };
-WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T)
+// e: shape_lane_entry(T, B.act[0] | B.act[1] << 4), requested when the batch was formed
+WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T, const U32& e)
 {
 	SlotPlace P;
-	const U32 lane = lane_id();
-	const U32 s = lane >> 4;
-	// the slots are the set bits of act[0] | act[1] << 4 in order
-	uint32_t m = B.act[0] | (B.act[1] << 4) | 0xF00u, pos[4]; // (the sentinel bits keep the search defined for unused slots)
-	for (int i = 0; i < 4; ++i) {
-		pos[i] = (uint32_t)__builtin_ctz(m);
-		m &= m - 1u;
-	}
-	const U32 posv = row_select4(pos[0], pos[1], pos[2], pos[3]);
-	P.k = posv & 3u;
-	P.blk = posv >> 2;
-	P.valid = s < U32(B.nslots);
+	P.e = e;
+	P.valid = (e & 8u) != U32(0u);
+	P.second = (e & 4u) != U32(0u);
 	// inclusive sums of the plane sizes over the slots (the value of a slot is the same in its 16 lanes)
 	U32 incl = R.size + scan_source(R.size, 4, 0u);
 	incl = incl + scan_source(incl, 5, 0u);
@@ -288,12 +290,9 @@ WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T)
 	const uint32_t pt = B.nslots ? readlane(incl, 16u * B.nslots - 1u) : 0u;
 	B.full[0] = p0 + (T - B.nact0);
 	B.full[1] = B.nblk > 1 ? pt - p0 + (T - (B.nslots - B.nact0)) : 0u;
-	const Pred second = P.blk != U32(0u);
-	P.act = sel(second, U32(B.act[1]), U32(B.act[0]));
-	P.first = sel(second, U32(B.first[1]), U32(B.first[0]));
-	// planes before mine in my block: SAME ones take a byte each, the others are the slots before mine
-	const U32 j = s - sel(second, U32(B.nact0), U32(0u));
-	P.pbase = U32(header_bytes(T)) + (P.k - j) + (incl - R.size - sel(second, U32(p0), U32(0u)));
+	P.first = sel(P.second, U32(B.first[1]), U32(B.first[0]));
+	// planes before mine in my block: SAME ones take a byte each (k - j of them), the others are the slots before mine
+	P.pbase = U32(header_bytes(T)) + ((e >> 4) & 3u) + (incl - R.size - sel(P.second, U32(p0), U32(0u)));
 	return P;
 }
 
@@ -330,20 +329,17 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	const uint32_t hs = header_bytes(T);
 	const U32 own = lane * 4u; // where lanes with nothing to write OR their zeros
 	WV_MARK("emit_nibbles");
-	const Pred second = P.blk != U32(0u);
-	const U32 bbase = sel(second, U32(base1), U32(base0));
+	const U32 bbase = sel(P.second, U32(base1), U32(base0));
 	const U32 pbase = bbase + P.pbase;
 	{
-		// One small write per lane of a slot: lane 0 the plane's type nibble (:1246-1257); lanes 1..3 the bytes of the SAME
-		// planes that follow the plane directly; lanes 4..7 of a block's first slot the SAME planes in front of it (:747-750).
-		const U32 after = r - 1u, before = r - 4u;
-		const Pred follows = (r >= U32(1u)) & (r < U32(4u)) & (P.k + r < U32(T)) & (((P.act >> (P.k + 1u)) & ((U32(1u) << r) - 1u)) == U32(0u));
-		const Pred leads = (r >= U32(4u)) & (r < U32(8u)) & (before < P.k) & ((P.act & ((U32(1u) << P.k) - 1u)) == U32(0u));
-		const U32 plane = sel(follows, P.k + r, before);
-		const U32 byte = (P.first >> (plane << 3)) & 0xFFu;
-		const U32 where = sel(follows, pbase + R.size + after, bbase + U32(hs) + before);
-		const Pred nib = r == U32(0u);
-		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type, byte), P.valid & (nib | follows | leads), own);
+		// One small write per lane of a slot, as the shape table says: lane 0 the plane's type nibble (:1246-1257); lanes 1..3
+		// the bytes of the SAME planes that follow the plane directly; lanes 4..7 of a block's first slot the SAME planes in
+		// front of it (:747-750).  Bit position: the table's constant from the block's start or from the end of the plane.
+		const U32 role = (P.e >> 6) & 3u;
+		const U32 byte = (P.first >> ((P.e >> 8) & 31u)) & 0xFFu;
+		const U32 from = sel(role == U32(2u), pbase + R.size, bbase);
+		const Pred nib = role == U32(1u);
+		put_small(out, from * 8u + ((P.e >> 13) & 63u), sel(nib, R.type, byte), role != U32(0u), own);
 	}
 	for (uint32_t i = 0; i < B.nblk; ++i) // a block without a slot: its SAME bytes (the type nibbles are all 0)
 		if (B.act[i] == 0) {
@@ -364,8 +360,7 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 		// mins rle mask (:765): bit r = min equals previous min
 		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
 		if (any(isnrle)) {
-			const uint64_t eqb = ballot(R.eq);
-			const U32 m16 = row_select4((uint32_t)eqb & 0xFFFFu, (uint32_t)(eqb >> 16) & 0xFFFFu, (uint32_t)(eqb >> 32) & 0xFFFFu, (uint32_t)(eqb >> 48));
+			const U32 m16 = row_ballot16(R.eq);
 			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
 		}
 	}
@@ -437,9 +432,13 @@ struct SlotBatch4 {
 };
 WV_HD uint32_t pick4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
 // base[q] receives the image offset of block q (the first one at img_base), *bbase that of its slot's block per lane
-WV_FN SlotPlace slot_rows_place4(const SlotRows& R, SlotBatch4& B, uint32_t T, const uint32_t hs, uint32_t img_base, uint32_t* base, U32* bbase)
+struct SlotPlace4 {
+	U32 pbase, k, blk, act, first;
+	Pred valid;
+};
+WV_FN SlotPlace4 slot_rows_place4(const SlotRows& R, SlotBatch4& B, uint32_t T, const uint32_t hs, uint32_t img_base, uint32_t* base, U32* bbase)
 {
-	SlotPlace P;
+	SlotPlace4 P;
 	const U32 lane = lane_id();
 	const U32 s = lane >> 4;
 	// the slots are the set bits of act[0] | act[1] << 4 | act[2] << 8 | act[3] << 12 in order
@@ -476,7 +475,7 @@ WV_FN SlotPlace slot_rows_place4(const SlotRows& R, SlotBatch4& B, uint32_t T, c
 }
 
 // The same for a wide batch: block q of the batch starts at byte base[q] of the image, bbase is that of the lane's slot.
-WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows& R, const SlotPlace& P, const SlotBatch4& B, const U32& bbase, const uint32_t* base)
+WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows& R, const SlotPlace4& P, const SlotBatch4& B, const U32& bbase, const uint32_t* base)
 {
 	const U32 lane = lane_id();
 	const U32 r = lane & 15u;
@@ -523,8 +522,7 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 		// mins rle mask (:765): bit r = min equals previous min
 		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
 		if (any(isnrle)) {
-			const uint64_t eqb = ballot(R.eq);
-			const U32 m16 = row_select4((uint32_t)eqb & 0xFFFFu, (uint32_t)(eqb >> 16) & 0xFFFFu, (uint32_t)(eqb >> 32) & 0xFFFFu, (uint32_t)(eqb >> 48));
+			const U32 m16 = row_ballot16(R.eq);
 			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
 		}
 	}

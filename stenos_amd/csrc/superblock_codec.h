@@ -7,6 +7,7 @@
 // (stenos/internal/block_compress.h:1152-1298, 1817-1878) and block_compress_partial (:947-1020).
 #pragma once
 #include "slot_codec.h"
+#include <type_traits>
 
 namespace codec {
 
@@ -188,16 +189,25 @@ struct StreamSink { // a contiguous stream in HBM (RunStream)
 // tight buffer.
 // slots: bytesoftype 2 and 4 go through the plane slots (slot_codec.h, up to two blocks per pass); false: the plane-group
 // loop at the bottom.
-template <class Sink>
-WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, bool slots)
+struct NoPassHook {
+	WV_MFN void operator()() const {}
+};
+// hook(): called after every pass of the slot loop (a wave may have other work waiting: kernels.hip, early store)
+template <class Sink, class Hook = NoPassHook>
+WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, bool slots, Hook hook = Hook())
 {
 	if (slots && (T == 2 || T == 4)) {
 		// Planes in slots (slot_codec.h): the non-constant planes of a block, and of its successor when they fit into
 		// the four slots together, are analysed and written by row lanes in one pass.
 		const uint32_t bs = 256 * T, hs = header_bytes(T);
 		uint32_t i = 0;
-		bool was_wide = false; // the last pass was a wide batch: the next one probably is, and asks for its four blocks at once
-		while (i < nblocks) {
+		// After a wide batch the next pass probably is one too and asks for its four blocks at once: passes that start below
+		// this block number do (0: none).
+		uint32_t wide_ahead = 0;
+		// One pass.  has_b (a type: known where the pass is compiled): a second block follows in the run -- every pass but a
+		// last single block, which gets a copy of the pass without the tests for it.
+		auto pass = [&](auto has_b_t) __attribute__((always_inline)) {
+			constexpr bool has_b = decltype(has_b_t)::value;
 			const uint8_t* a = src + (uint64_t)i * bs;
 			const uint8_t* b = a + bs;
 			WV_MARK("load_block");
@@ -206,17 +216,16 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			{
 				// both blocks are requested at once, straight into registers; when the second one is not paired after all,
 				// its load has at least brought it closer for the next round
-				const bool has_b = i + 1 < nblocks;
 				const RawBlock ea = load_raw_block(a, T);
 				RawBlock eb, ec, ed;
 				if (has_b)
 					eb = load_raw_block(b, T);
-				const bool early = was_wide && i + 3 < nblocks;
+				const bool early = has_b && i < wide_ahead;
 				if (early) {
 					ec = load_raw_block(b + bs, T);
 					ed = load_raw_block(b + 2 * bs, T);
 				}
-				was_wide = false;
+				wide_ahead = 0;
 				WV_MARK("block_begin");
 #if defined(STENOS_PAD_CHEAP) || defined(STENOS_PAD_OTHER) || defined(STENOS_PAD_SALU)
 				{ // timing experiments only (tools/build_variant.sh): what an instruction of each class costs at the margin
@@ -265,6 +274,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					keys0 = lz_distinct_keys_fast<2>(lds, M, ea.e);
 				if (T == 4 && nblk > 1 && B.nslots - B.nact0 >= 2)
 					keys1 = lz_distinct_keys_fast<2>(lds, M, eb.e);
+				// what the row lanes need to know about a pass of this shape: requested now, used behind the analysis
+				const U32 shape_e = shape_lane_entry(T, B.act[0] | (B.act[1] << 4));
 				write_slots_fast(lds, M, ea, T, B.act[0], 0);
 				if (nblk > 1)
 					write_slots_fast(lds, M, eb, T, B.act[1], B.nact0);
@@ -273,7 +284,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				// they have at most one such plane themselves (a wide batch, slot_codec.h).
 				SlotBatch4 W;
 				W.nblk = 0;
-				if (B.nslots <= 2) { WV_NESTED(); if (nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
+				if (has_b && B.nslots <= 2) { WV_NESTED(); if (nblk == 2 && B.nact0 <= 1 && B.nslots - B.nact0 <= 1 && i + 2 < nblocks) {
 					const bool has_d = i + 3 < nblocks;
 					if (!early) {
 						ec = load_raw_block(b + bs, T);
@@ -298,7 +309,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 							}
 						}
 						nblk = W.nblk;
-						was_wide = true;
+						wide_ahead = nblocks > 3 ? nblocks - 3 : 0; // (i + 3 < nblocks)
 					}
 				} }
 				wave_sync();
@@ -314,7 +325,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					}
 					uint32_t base[4];
 					U32 bbase;
-					const SlotPlace P = slot_rows_place4(R, W, T, hs, sink.base(), base, &bbase);
+					const SlotPlace4 P = slot_rows_place4(R, W, T, hs, sink.base(), base, &bbase);
 					const uint32_t total = base[3] + (W.nblk > 3 ? hs + W.full[3] : 0u) - base[0];
 					if (sink.writes) {
 						image_reset_fixed(lds, M, T);
@@ -322,7 +333,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					}
 					sink.append(lds, M, total);
 					i += nblk;
-					continue;
+					hook();
+					return;
 				}
 				SlotRows R;
 				if (B.nslots)
@@ -334,7 +346,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					R.emitmin = R.eq = pred_all(false);
 				}
 				WV_MARK("plane_offsets");
-				const SlotPlace P = slot_rows_place(R, B, T);
+				const SlotPlace P = slot_rows_place(R, B, T, shape_e);
 				if (T == 4) {
 					// Those that pass the rejection tests.  The key counts cover the first 40 values (most blocks fail there); a block
 					// they do not turn away is looked at again: first the test that turns noise and floats away (values that hardly
@@ -362,7 +374,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					sink.append(lds, M, size0 + size1);
 					WV_MARK("block_end");
 					i += nblk;
-					continue;
+					hook();
+					return;
 				}
 			}
 			// a mini-LZ attempt: the general block encoder, one block at a time
@@ -374,7 +387,11 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				sink.append(lds, M, r.size);
 			}
 			i += nblk;
-		}
+		};
+		while (i + 1 < nblocks)
+			pass(std::true_type());
+		if (i < nblocks)
+			pass(std::false_type());
 		return;
 	}
 	for (uint32_t i = 0; i < nblocks; ++i) {
@@ -388,7 +405,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 
 // ... into a staging stream at stage (16-byte aligned, room for nblocks * max_block_bytes(T) + 16); returns the bytes
 // (stage == nullptr: nothing is written, only the bytes are counted)
-WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true)
+template <class Hook = NoPassHook>
+WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true, Hook hook = Hook())
 {
 	StreamSink sink;
 	sink.rs.base = stage;
@@ -396,7 +414,7 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 	sink.writes = stage != nullptr;
 	if (sink.writes)
 		stream_begin(lds, L.out);
-	encode_blocks_to(sink, lds, L, T, src, nblocks, slots);
+	encode_blocks_to(sink, lds, L, T, src, nblocks, slots, hook);
 	if (sink.writes)
 		stream_flush(sink.rs, lds, L.out);
 	return sink.rs.pos;

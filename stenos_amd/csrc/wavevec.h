@@ -22,6 +22,7 @@
 #define WV_FN static inline
 #define WV_MFN inline
 #define WV_HD static inline
+#define WV_TABLE static const
 #define WV_MARK(name)
 #define WV_NESTED()
 namespace wv {
@@ -237,6 +238,14 @@ WV_FN uint64_t ballot(const Pred& p)
 	return m;
 }
 WV_FN uint32_t readlane(const U32& a, uint32_t lane) { return a.l[lane & 63]; }
+// bit r of lane 16k + q: p in lane 16k + r (the ballot of the lane's own group of 16 lanes)
+WV_FN U32 row_ballot16(const Pred& p)
+{
+	const uint64_t m = ballot(p);
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(m >> (i & 48)) & 0xFFFFu;
+	return r;
+}
 // 1 when the lane mask is not empty, else 0
 WV_FN uint32_t mask_nonzero(uint64_t m) { return m ? 1u : 0u; }
 template <uint32_t BIT>
@@ -490,6 +499,7 @@ WV_FN void lds_st128(Lds m, const U32& a, const U128& v, const Pred& p)
 #include <hip/hip_runtime.h>
 #define WV_FN static __device__ __forceinline__
 #define WV_MFN __device__ __forceinline__
+#define WV_TABLE static __device__ const
 #define WV_HD static __host__ __device__ __forceinline__
 // a comment line in the generated ISA (tools/isa_regions.py counts the instructions between marks); no code
 #define WV_MARK(name) asm volatile("; MARK " name)
@@ -537,6 +547,8 @@ WV_FN U32 funnel_shr(U32 hi, U32 lo, U32 sh) { return __builtin_amdgcn_alignbit(
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN U32 perm_bytes_v(U32 hi, U32 lo, U32 selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __builtin_amdgcn_ballot_w64(p); }
+// bit r of lane 16k + q: p in lane 16k + r (the ballot of the lane's own group of 16 lanes): one 64-bit shift by a per-lane amount
+WV_FN U32 row_ballot16(Pred p) { return (U32)(__builtin_amdgcn_ballot_w64(p) >> (lane_id_plain() & 48u)) & 0xFFFFu; }
 WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }
 // 1 when the lane mask is not empty, else 0 -- as an integer in a scalar register (a C++ bool would be kept as a
 // lane mask and turned into a number through vector registers)
