@@ -162,6 +162,42 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 	return CHAIN_FAILED;
 }
 
+#ifdef STENOS_COPY_CALL
+// The copy of a finished superblock as a function of its own: outside the block loop's register allocation it can keep
+// STENOS_COPY_CALL rounds of loads in flight (48 registers for 12) without costing the loop a spill.
+__device__ __attribute__((noinline)) void store_run_call(uint8_t* dst, const uint8_t* src, uint32_t n) { copy_g2g_wide<STENOS_COPY_CALL>(dst, src, n); }
+__device__ __forceinline__ void fused_store_call(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, const uint32_t* run_size, const uint8_t* stage_w)
+{
+	const U32 lane = lane_id();
+	uint32_t code;
+	const uint32_t csize = fused_superblock_size(j, run_size, &code) - 4;
+	uint8_t* base = j.dst + off;
+	if (w == 0) {
+		if (s == 0 && j.shift_byte != 0xFFFFFFFFu) {
+			const uint64_t v = (uint64_t)j.shift_byte | (j.total_bytes << 8);
+			gst8(j.dst, lane, (U32((uint32_t)v) >> ((lane & 3u) << 3)), lane < U32(4u));
+			gst8(j.dst, lane, (U32((uint32_t)(v >> 32)) >> ((lane & 3u) << 3)), (lane >= U32(4u)) & (lane < U32(8u)));
+			if (j.shift_byte == 255)
+				gst8(j.dst + 8, lane, U32(j.sb_bytes) >> ((lane & 3u) << 3), lane < U32(4u));
+		}
+		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
+	}
+	if (code == 1) {
+		uint32_t before = 0;
+		for (uint32_t k = 0; k < w; ++k)
+			before += run_size[k];
+		store_run_call(base + 4 + before, stage_w, run_size[w]);
+	}
+	else {
+		uint32_t b0, b1;
+		fused_run_range(j.bps, w, &b0, &b1);
+		const uint32_t bs = 256 * j.T;
+		store_run_call(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
+	}
+}
+#define fused_store fused_store_call
+#endif
+
 // Workgroup 0: the scanner.  Every other workgroup: FUSED_WAVES wavefronts that take superblocks one after the other
 // until none is left -- encode (each wave a run of consecutive blocks into its staging stream), publish the size, then
 // store the previous superblock at its offset (pipeline.h, fused_store): by then the scanner has normally passed it.
@@ -197,7 +233,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 		// readfirstlane yields an int: go through uint32_t or values beyond 2^31 get sign-extended
 		const uint64_t s = (uint32_t)__builtin_amdgcn_readfirstlane(shared[parity]);
 		const bool work = s < nsb;
-		volatile uint32_t* runs = shared + 8 + 4 * parity;
+		volatile uint32_t* runs = shared + 8 + FUSED_WAVES * parity;
 		uint32_t run_size[FUSED_WAVES];
 		if (work) {
 			// A superblock whose block stream comes out larger than its input is stored as a copy (stenos.cpp:609-610) and
@@ -239,7 +275,18 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 			const uint64_t off = chain_wait(j, prev);
 			if (off == CHAIN_FAILED)
 				shared[2] = 1;
-#ifndef STENOS_EXP_NO_STORE // (timing experiment, wrong frames: what the staging read and the frame write cost)
+#ifdef STENOS_EXP_DIRECT // (timing experiment, wrong frames: the run's bytes are written -- not copied -- to their place in the frame)
+			else {
+				uint32_t before = 0;
+				for (uint32_t k = 0; k < w; ++k)
+					before += prev_run[k];
+				uint8_t* to = j.dst + ((off + 4 + before + 15) & ~15ull);
+				const uint32_t groups = prev_run[w] >> 4;
+				for (uint32_t o = 0; o < groups; o += 64)
+					if (o + (threadIdx.x & 63u) < groups)
+						*(uint4*)(to + (o + (threadIdx.x & 63u)) * 16u) = make_uint4(o, w, groups, 1u);
+			}
+#elif !defined(STENOS_EXP_NO_STORE) // (timing experiment, wrong frames: what the staging read and the frame write cost)
 			else
 				fused_store(j, prev, w, off, prev_run, stage_w + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap);
 #endif
@@ -365,7 +412,7 @@ hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1,
 template <uint32_t TT>
 static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream)
 {
-	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 64;
+	const size_t lds = FUSED_WAVES * stenos_k_encode_lds_bytes(j.T) + 32 + 8 * FUSED_WAVES;
 	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
@@ -389,13 +436,13 @@ hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t
 	}
 }
 // the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)
-bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 64 <= 160u * 1024u; }
+bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 32 + 8 * FUSED_WAVES <= 160u * 1024u; }
 // encoder workgroups of the fused kernel: as many as stay resident (they take superblocks until none is left)
 uint32_t stenos_k_fused_groups(uint64_t nsb)
 {
 	if (FUSED_TICKETS)
 		return (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS);
-	const uint64_t resident = (uint64_t)stenos_k_cu_count() * 8;
+	const uint64_t resident = (uint64_t)stenos_k_cu_count() * (32 / FUSED_WAVES); // eight waves per SIMD
 	return (uint32_t)(nsb < resident ? nsb : resident);
 }
 // two staging buffers per workgroup

@@ -135,6 +135,7 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 	const uint32_t r = rs.pos & 15u;
 	const uint32_t groups = (r + n) >> 4;
 	uint8_t* g = rs.base + (rs.pos - r);
+#ifndef STENOS_EXP_DIRECT // (timing experiment, wrong frames: nothing is staged; kernels.hip writes bytes of the right size at the right place)
 	{ // the first 64 groups without a loop around them: that is all of them unless the blocks hardly compress
 		Pred p = lane < U32(groups);
 		gst128(g, lane * 16u, lds_ld128(lds, U32(out) + sel(p, lane, U32(0u)) * 16u), p);
@@ -144,6 +145,9 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 		Pred p = k < U32(groups);
 		gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
 	}
+#else
+	(void)g;
+#endif
 	// the group behind them (its bytes past the encoding are zero) waits in front of the image
 	Pred t = lane < U32(4u);
 	U32 a = sel(t, lane, U32(0u)) * 4u;
