@@ -23,7 +23,10 @@ STENOS_EXPORT int stenos_hip_device_count(void);
  * The context allocates and keeps it; this is for capacity planning. */
 STENOS_EXPORT size_t stenos_hip_workspace_bytes(size_t bytesoftype, size_t bytes);
 
-/* Compress `bytes` of device memory into a Stenos frame in device memory.  Uses ctx's level and
+/* Compress `bytes` of device memory into a Stenos frame in device memory.  The bytes of d_dst behind the returned frame size
+ * (and inside dst_size) are scratch: incompressible stretches are put in place before their offsets are final
+ * (csrc/kernels.hip, speculative copy), so that range may hold leftovers.  Nothing is written at or past dst_size, and
+ * the host-pointer calls of stenos.h only copy the frame back.  Uses ctx's level and
  * block-size settings; a time limit (stenos_set_max_nanoseconds) is a feature of the host-pointer calls only:
  * with one set these entry points return STENOS_ERROR_INVALID_PARAMETER.  Enqueues on `stream`, then waits for the 8-byte size to come back.
  * Returns the frame size or an error code (test with stenos_has_error). */

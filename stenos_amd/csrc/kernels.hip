@@ -83,6 +83,10 @@ constexpr uint32_t FUSED_OCCUPANCY = STENOS_FUSED_OCCUPANCY;
 #ifndef STENOS_FUSED_TICKETS
 #define STENOS_FUSED_TICKETS 0
 #endif
+#ifndef STENOS_FUSED_SPECULATE
+#define STENOS_FUSED_SPECULATE 1
+#endif
+constexpr bool FUSED_SPECULATE = STENOS_FUSED_SPECULATE != 0; // raw bytes of measured superblocks go straight to where a copy behind copies stands
 constexpr uint32_t FUSED_TICKETS = STENOS_FUSED_TICKETS; // superblocks per encoder workgroup; 0: as many as it gets (a resident grid) // waves per SIMD the register allocation of the fused kernel aims at
 
 __device__ inline void chain_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -162,42 +166,6 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 	return CHAIN_FAILED;
 }
 
-#ifdef STENOS_COPY_CALL
-// The copy of a finished superblock as a function of its own: outside the block loop's register allocation it can keep
-// STENOS_COPY_CALL rounds of loads in flight (48 registers for 12) without costing the loop a spill.
-__device__ __attribute__((noinline)) void store_run_call(uint8_t* dst, const uint8_t* src, uint32_t n) { copy_g2g_wide<STENOS_COPY_CALL>(dst, src, n); }
-__device__ __forceinline__ void fused_store_call(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, const uint32_t* run_size, const uint8_t* stage_w)
-{
-	const U32 lane = lane_id();
-	uint32_t code;
-	const uint32_t csize = fused_superblock_size(j, run_size, &code) - 4;
-	uint8_t* base = j.dst + off;
-	if (w == 0) {
-		if (s == 0 && j.shift_byte != 0xFFFFFFFFu) {
-			const uint64_t v = (uint64_t)j.shift_byte | (j.total_bytes << 8);
-			gst8(j.dst, lane, (U32((uint32_t)v) >> ((lane & 3u) << 3)), lane < U32(4u));
-			gst8(j.dst, lane, (U32((uint32_t)(v >> 32)) >> ((lane & 3u) << 3)), (lane >= U32(4u)) & (lane < U32(8u)));
-			if (j.shift_byte == 255)
-				gst8(j.dst + 8, lane, U32(j.sb_bytes) >> ((lane & 3u) << 3), lane < U32(4u));
-		}
-		gst8(base, lane, U32(code | (csize << 8)) >> ((lane & 3u) << 3), lane < U32(4u));
-	}
-	if (code == 1) {
-		uint32_t before = 0;
-		for (uint32_t k = 0; k < w; ++k)
-			before += run_size[k];
-		store_run_call(base + 4 + before, stage_w, run_size[w]);
-	}
-	else {
-		uint32_t b0, b1;
-		fused_run_range(j.bps, w, &b0, &b1);
-		const uint32_t bs = 256 * j.T;
-		store_run_call(base + 4 + (uint64_t)b0 * bs, j.src + (s * j.bps + b0) * (uint64_t)bs, (b1 - b0) * bs);
-	}
-}
-#define fused_store fused_store_call
-#endif
-
 // Workgroup 0: the scanner.  Every other workgroup: FUSED_WAVES wavefronts that take superblocks one after the other
 // until none is left -- encode (each wave a run of consecutive blocks into its staging stream), publish the size, then
 // store the previous superblock at its offset (pipeline.h, fused_store): by then the scanner has normally passed it.
@@ -219,6 +187,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 	uint32_t b0, b1;
 	fused_run_range(j.bps, w, &b0, &b1);
 	uint64_t prev = CHAIN_FAILED; // superblock that is encoded but not stored yet
+	bool prev_spec = false;       // ... and its raw bytes were put where a copy behind copies goes
 	uint32_t prev_run[FUSED_WAVES];
 	bool guess_copy = false; // the workgroup's last superblock ended up as a copy
 	if (threadIdx.x == 0)
@@ -235,6 +204,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 		const bool work = s < nsb;
 		volatile uint32_t* runs = shared + 8 + FUSED_WAVES * parity;
 		uint32_t run_size[FUSED_WAVES];
+		bool spec_now = false;
 		if (work) {
 			// A superblock whose block stream comes out larger than its input is stored as a copy (stenos.cpp:609-610) and
 			// the stream is thrown away: after such a superblock the next one is only measured (nothing written, nothing
@@ -247,7 +217,17 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 #else
 				const bool measure = guess_copy && attempt == 0;
 #endif
-				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to);
+				// Speculative copy.  A superblock that is only measured is expected to be stored as a copy, and if every superblock
+				// before it is one too its place in the frame is known: header + s * (superblock + 4).  Its raw bytes go there
+				// while they pass through the registers of the measuring pass; when the offset arrives and is that place, the copy
+				// (a second read of the input, a second pass over 128 KiB) is not needed.  A wrong guess costs nothing but the
+				// stores: the bytes land at or behind the superblock's real place, inside the frame's worst case, and whoever owns
+				// those bytes writes them later -- later superblocks learn their offsets only after this one has published its
+				// size, which it does after its stores -- write-through: the XCDs' L2s are not coherent -- have completed.
+				uint8_t* const spec_to = measure && FUSED_SPECULATE ? j.dst + j.header_bytes + s * (uint64_t)(j.sb_bytes + 4) + 4 + (uint64_t)b0 * (256 * T) : nullptr;
+				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to, true, NoPassHook(), spec_to);
+				if (spec_to)
+					gst_through_wait(); // (write-through stores: in memory before the size is published)
 				if ((threadIdx.x & 63u) == 0)
 					runs[w] = n;
 				__syncthreads();
@@ -264,6 +244,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 					continue;
 				}
 				guess_copy = code == 6;
+				spec_now = measure && FUSED_SPECULATE; // (its raw bytes stand at the speculated place; code is 6 here)
 				if (threadIdx.x == 0)
 					chain_put(size + s, bytes);
 				break;
@@ -288,12 +269,14 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_supe
 			}
 #elif !defined(STENOS_EXP_NO_STORE) // (timing experiment, wrong frames: what the staging read and the frame write cost)
 			else
-				fused_store(j, prev, w, off, prev_run, stage_w + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap);
+				fused_store(j, prev, w, off, prev_run, stage_w + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap,
+					    prev_spec && off == j.header_bytes + prev * (uint64_t)(j.sb_bytes + 4));
 #endif
 		}
 		if (!work)
 			return;
 		prev = s;
+		prev_spec = spec_now;
 		for (uint32_t k = 0; k < FUSED_WAVES; ++k)
 			prev_run[k] = run_size[k];
 	}

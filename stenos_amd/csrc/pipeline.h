@@ -274,8 +274,9 @@ WV_HD uint32_t fused_superblock_size(const FrameJob& j, const uint32_t* run_size
 	return 4 + (*code == 1 ? csize : j.sb_bytes);
 }
 
-// wave w's share of writing superblock s at frame offset off
-WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, const uint32_t* run_size, const uint8_t* stage_w)
+// wave w's share of writing superblock s at frame offset off.  payload_in_place: a copy whose raw bytes stand there already
+// (kernels.hip, speculative copy): only the headers are left to write.
+WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, const uint32_t* run_size, const uint8_t* stage_w, bool payload_in_place = false)
 {
 	const U32 lane = lane_id();
 	uint32_t code;
@@ -298,7 +299,7 @@ WV_FN void fused_store(const FrameJob& j, uint64_t s, uint32_t w, uint64_t off, 
 			before += run_size[k];
 		copy_g2g_wide(base + 4 + before, stage_w, run_size[w]);
 	}
-	else {
+	else if (!payload_in_place) {
 		uint32_t b0, b1;
 		fused_run_range(j.bps, w, &b0, &b1);
 		const uint32_t bs = 256 * j.T;

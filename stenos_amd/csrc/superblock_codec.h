@@ -177,6 +177,18 @@ WV_FN void stream_flush(const RunStream& rs, Lds lds, uint32_t out)
 struct StreamSink { // a contiguous stream in HBM (RunStream)
 	RunStream rs;
 	bool writes; // false: sizes only, nothing is written (a superblock that is expected to end up as a copy, kernels.hip)
+	// A superblock that is only measured because it will probably be stored as a copy: where its raw bytes would go in that
+	// case (kernels.hip, speculative copy); the blocks are stored there from the registers they were loaded into anyway.
+	// nullptr: nowhere.  raw_ok turns false when a block went another way (the general encoder: not stored).
+	uint8_t* raw_to = nullptr;
+	bool raw_ok = true;
+	WV_MFN void raw(const RawBlock& b, uint32_t T, uint32_t block)
+	{
+		if (T == 2)
+			gst64_through(raw_to + (uint64_t)block * 512u, lane_id() * 8u, b.e.x, b.e.y);
+		else
+			gst128_through(raw_to + (uint64_t)block * 1024u, lane_id() * 16u, b.e);
+	}
 	WV_MFN Layout at(const Layout& L) const { return L; }
 	WV_MFN uint32_t base() const { return rs.pos & 15u; }
 	WV_MFN void append(Lds lds, const Layout& L, uint32_t n)
@@ -316,6 +328,15 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 						wide_ahead = nblocks > 3 ? nblocks - 3 : 0; // (i + 3 < nblocks)
 					}
 				} }
+				if (sink.raw_to) { // (measured only, probably a copy: the raw bytes go where the copy would put them)
+					sink.raw(ea, T, i);
+					if (nblk > 1)
+						sink.raw(eb, T, i + 1);
+					if (nblk > 2)
+						sink.raw(ec, T, i + 2);
+					if (nblk > 3)
+						sink.raw(ed, T, i + 3);
+				}
 				wave_sync();
 				if (W.nblk) {
 					SlotRows R;
@@ -383,6 +404,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 			}
 			// a mini-LZ attempt: the general block encoder, one block at a time
+			// (the raw bytes of a measured superblock have been put in place already, above)
 			for (uint32_t q = 0; q < nblk; ++q) {
 				load_block(lds, L.in, q ? b : a, bs);
 				wave_sync();
@@ -401,6 +423,11 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 	for (uint32_t i = 0; i < nblocks; ++i) {
 		load_block(lds, L.in, src + (uint64_t)i * (256 * T), 256 * T);
 		wave_sync();
+		if (sink.raw_to) // (measured only, probably a copy: the raw bytes go where the copy would put them)
+			for (uint32_t o = 0; o < 256 * T; o += 1024) {
+				const U32 off = umin(U32(o) + lane_id() * 16u, U32(256 * T - 16u)); // (lanes beyond the end repeat the last group)
+				gst128_through(sink.raw_to + (uint64_t)i * (256 * T), off, lds_ld128(lds, U32(L.in) + off));
+			}
 		const Layout M = sink.at(L);
 		const BlockInfo r = encode_full_block(lds, M, T, true, sink.base());
 		sink.append(lds, M, r.size);
@@ -409,13 +436,16 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 
 // ... into a staging stream at stage (16-byte aligned, room for nblocks * max_block_bytes(T) + 16); returns the bytes
 // (stage == nullptr: nothing is written, only the bytes are counted)
+// raw_to (only without a stage): the blocks' raw bytes are stored there on the way (StreamSink::raw_to)
 template <class Hook = NoPassHook>
-WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true, Hook hook = Hook())
+WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true, Hook hook = Hook(),
+			  uint8_t* raw_to = nullptr)
 {
 	StreamSink sink;
 	sink.rs.base = stage;
 	sink.rs.pos = 0;
 	sink.writes = stage != nullptr;
+	sink.raw_to = stage ? nullptr : raw_to;
 	if (sink.writes)
 		stream_begin(lds, L.out);
 	encode_blocks_to(sink, lds, L, T, src, nblocks, slots, hook);

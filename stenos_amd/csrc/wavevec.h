@@ -458,6 +458,9 @@ WV_FN void gst128_unaligned(uint8_t* g, const U32& off, const U128& v, const Pre
 WV_FN void gst128_streamed(uint8_t* g, const U32& off, const U128& v, const Pred& p) { gst128(g, off, v, p); }
 WV_FN void gst8_streamed(uint8_t* g, const U32& off, const U32& v, const Pred& p) { gst8(g, off, v, p); }
 WV_FN void gst64_unaligned(uint8_t* g, const U32& off, const U32& lo, const U32& hi, const Pred& p) { gst64(g, off, lo, hi, p); }
+WV_FN void gst128_through(uint8_t* g, const U32& off, const U128& v) { gst128(g, off, v, pred_all(true)); }
+WV_FN void gst64_through(uint8_t* g, const U32& off, const U32& lo, const U32& hi) { gst64(g, off, lo, hi, pred_all(true)); }
+WV_FN void gst_through_wait() {}
 // wave-uniform scalar accesses to global memory
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *p; }
 WV_FN uint32_t gload_uniform8(const uint8_t* p) { return *p; }
@@ -953,7 +956,9 @@ WV_FN void gst128_streamed(uint8_t* g, U32 off, const U128& v, Pred p)
 	// (g is the same for all lanes: a scalar base and a 32-bit lane offset, as the compiler addresses its own stores)
 	wv_u4 d = { v.x, v.y, v.z, v.w };
 	uint64_t save;
-	asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_mov_b64 exec, %0"
+	// (two wait states behind the store: on gfx940 and later a store of more than 8 bytes still reads its data registers that
+	// long, and the compiler's hazard recognizer does not look into an asm statement -- block_codec.h found this the hard way)
+	asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_nop 0\n\ts_mov_b64 exec, %0"
 		     : "=&s"(save)
 		     : "s"(ballot(p)), "v"(off), "v"(d), "s"(uniform_pointer(g))
 		     : "memory", "scc");
@@ -974,6 +979,28 @@ WV_FN void gst128(uint8_t* g, U32 off, const U128& v, Pred p)
 		gst128_unaligned(g, off, v, p);
 }
 #endif
+// Write-through stores (all lanes): the bytes go to memory, past this XCD's L2 -- the per-XCD L2s are not coherent with
+// each other -- so that a workgroup on another XCD that overwrites them later wins whatever the order of the write-backs
+// (kernels.hip, speculative copy).  The compiler does not count them: gst_through_wait() waits for them.
+WV_FN uint8_t* wave_base(uint8_t* g) // (all lanes hold the same pointer: say so)
+{
+	const uint64_t a = (uint64_t)g;
+	return (uint8_t*)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32));
+}
+WV_FN void gst128_through(uint8_t* g, U32 off, const U128& v)
+{
+	wv_u4 d = { v.x, v.y, v.z, v.w };
+	// (s_nop 1: a store of more than 8 bytes still reads its data registers for two more cycles on gfx940 and later, and the compiler's hazard
+	// recognizer does not look into an asm statement: without it the instruction behind may overwrite the first of them)
+	asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(off), "v"(d), "s"(wave_base(g)) : "memory");
+}
+WV_FN void gst64_through(uint8_t* g, U32 off, U32 lo, U32 hi)
+{
+	typedef uint32_t wv_pair __attribute__((ext_vector_type(2)));
+	wv_pair d = { lo, hi };
+	asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(off), "v"(d), "s"(wave_base(g)) : "memory");
+}
+WV_FN void gst_through_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 // wave-uniform scalar accesses to global memory (stores by one lane)
 WV_FN uint32_t gload_uniform(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 WV_FN uint32_t gload_uniform8(const uint8_t* p) { return *(const volatile uint8_t*)p; }

@@ -288,6 +288,16 @@ void emul_copy_g2g_wide(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g_w
 size_t emul_lds_bytes_encode(size_t T) { return make_layout((uint32_t)T, true).total; }
 size_t emul_lds_bytes_decode(size_t T) { return make_dec_layout((uint32_t)T).total; }
 
+// a run that is only measured while its raw bytes are put where a copy would stand (kernels.hip, speculative copy)
+size_t emul_measure_run(const uint8_t* src, size_t T, size_t nblocks, uint8_t* raw_out)
+{
+	Layout L = make_layout((uint32_t)T, true);
+	uint8_t* lds = alloc_lds(L.total);
+	const uint32_t n = encode_run(lds, L, (uint32_t)T, src, (uint32_t)nblocks, nullptr, true, NoPassHook(), raw_out);
+	free(lds);
+	return n;
+}
+
 // ---- walk.h: the parallel header walk, its kernels replayed lane by lane (walk_kernels.hip) --------------------------
 // off[0 .. nsb], *status |= 1 for a truncated chain as the serial walk says.  Returns the number of segments (0: the plan
 // chose the serial walk) or -1 when the speculation failed and the serial walk has to run.

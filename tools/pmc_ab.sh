@@ -8,14 +8,16 @@ P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 for v in "$@"; do
   out=$R/gpurun_out/pmcab_${v}_${kind}$T
   rm -rf $out
-  STENOS_LIB_PATH=$R/stenos_amd/lib/exp/libstenos_$v.so timeout -k 10 150 rocprofv3 --pmc $P1 --output-format csv -d $out -- python3 $R/tools/one_encode.py $kind $T > $out.log 2>&1
+  STENOS_LIB_PATH=$R/stenos_amd/lib/exp/libstenos_$v.so timeout -k 10 150 rocprofv3 --pmc $P1 --output-format csv -d $out -- python3 $R/tools/one_encode.py $kind $T $PMC_DECODE > $out.log 2>&1
   python3 - "$out" "$v" "$kind" "$T" <<'PY'
 import csv, glob, sys, collections
 out, v, kind, T = sys.argv[1:5]
+import os
+KERNEL = os.environ.get("PMC_KERNEL", "encode_superblocks")
 agg = collections.defaultdict(float)
 for p in glob.glob(out + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(p)):
-        if "encode_superblocks" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
 blocks = (1 << 30) / (256 * int(T))
 if agg:
