@@ -80,6 +80,13 @@ STENOS_EXPORT int stenos_hip_last_devices(stenos_context* ctx);
  * boxes); fail_lane >= 0 keeps that lane from running, as if its device could not be made current (-1: none). */
 STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane);
 
+/* Levels >= 2 (and bytesoftype 1) run a strategy layer on the host around the GPU passes (LZ4-dry estimates, zstd).  Wall
+ * time per stage in milliseconds, summed over the calls on ctx since the last reset: out[0] GPU block pass + verdicts and
+ * samples to the host, [1] estimates, [2] waiting for block streams from the device, [3] zstd, [4] frame layout, [5] waiting
+ * for the frame's upload (device destinations), [6] zstd inflate (decompression), [7] device decode of the inflated
+ * superblocks.  Transfers that are hidden behind zstd do not show.  Returns the number of stages; reset != 0 clears the sums. */
+STENOS_EXPORT int stenos_hip_stage_ms(stenos_context* ctx, double* out, int n, int reset);
+
 /* Tests only: serial != 0 makes frames that come without an index be walked by one lane (the serial walk that the
  * parallel one of walk.h is proven against, and falls back to). */
 STENOS_EXPORT void stenos_hip_test_walk(stenos_context* ctx, int serial);

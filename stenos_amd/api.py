@@ -78,6 +78,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "stenos_hip_set_devices": (None, [vp, c_int]),
         "stenos_hip_test_lanes": (None, [vp, c_int, c_int]),
         "stenos_hip_test_walk": (None, [vp, c_int]),
+        "stenos_hip_stage_ms": (c_int, [vp, ctypes.POINTER(ctypes.c_double), c_int, c_int]),
         "stenos_hip_fused_fallbacks": (c_int, [vp, c_int]),
         "stenos_hip_workspace_bytes": (sz, [sz, sz]),
         "stenos_hip_compress": (sz, [vp, vp, sz, sz, vp, sz, vp]),
@@ -152,6 +153,13 @@ class Stenos:
     def kernel_ms(self, which: int) -> float:
         """elapsed ms of the last encode_blocks (0) / decode_superblocks (1) launch"""
         return self.lib.stenos_hip_kernel_ms(self.ctx, which)
+
+    def stage_ms(self, reset: bool = True):
+        """wall milliseconds per stage of the levels >= 2 strategy layer since the last reset (include/stenos_hip.h)"""
+        names = ("gpu_pass", "estimates", "wait_block_streams", "zstd", "layout", "wait_upload", "inflate", "device_decode")
+        buf = (ctypes.c_double * len(names))()
+        self.lib.stenos_hip_stage_ms(self.ctx, buf, len(names), 1 if reset else 0)
+        return {k: round(buf[i], 3) for i, k in enumerate(names)}
 
     def last_index(self):
         n = c_size_t(0)

@@ -273,6 +273,30 @@ hipError_t stenos_k_launch_shuffle(const uint8_t* src, uint8_t* dst, uint32_t T,
 	return hipGetLastError();
 }
 
+// Levels >= 2, device destinations: the superblocks of a batch come out of the host's zstd in slots of `stride` bytes (piece k
+// at src + k * stride, size[k] bytes, [code][csize:3] header included); each goes to dst + off[k] -- the frame is laid out
+// on the device instead of by the host's threads.  One workgroup per piece; the source slots are 16-byte aligned, the
+// destination is wherever the frame puts the piece (unaligned 16-byte stores).
+__global__ __launch_bounds__(256) void gather_pieces_kernel(const uint8_t* __restrict__ src, uint64_t stride, const uint64_t* __restrict__ off,
+							     const uint64_t* __restrict__ size, uint8_t* __restrict__ dst)
+{
+	typedef uint4 __attribute__((aligned(1))) uint4_u;
+	const uint8_t* from = src + (uint64_t)blockIdx.x * stride;
+	uint8_t* to = dst + off[blockIdx.x];
+	const uint64_t n = size[blockIdx.x], groups = n >> 4;
+	for (uint64_t g = threadIdx.x; g < groups; g += 256)
+		*(uint4_u*)(to + g * 16) = *(const uint4*)(from + g * 16);
+	for (uint64_t b = groups * 16 + threadIdx.x; b < n; b += 256)
+		to[b] = from[b];
+}
+hipError_t stenos_k_launch_gather_pieces(const uint8_t* src, uint64_t stride, const uint64_t* off, const uint64_t* size, uint32_t count, uint8_t* dst, hipStream_t stream)
+{
+	if (count == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(gather_pieces_kernel, dim3(count), dim3(256), 0, stream, src, stride, off, size, dst);
+	return hipGetLastError();
+}
+
 hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t bytes, bool inverse, hipStream_t stream)
 {
 	if (bytes == 0)

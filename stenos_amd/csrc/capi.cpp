@@ -174,18 +174,26 @@ struct HostBuf {
 };
 
 // builds with -DSTENOS_HOST_TRACE: wall-clock of the host phases of the strategy layer on stderr (diagnostics)
+// Wall time of the stages of a levels >= 2 call (the host's strategy layer around the GPU passes), summed per stage name
+// into the context: stenos_hip_stage_ms() reads them (bench.py reports them); -DSTENOS_HOST_TRACE also prints every mark.
+enum StageId { STAGE_GPU_PASS = 0, STAGE_ESTIMATES, STAGE_BLOCKS_TO_HOST, STAGE_ZSTD, STAGE_LAYOUT, STAGE_UPLOAD, STAGE_INFLATE, STAGE_DEVICE_FINISH, STAGE_COUNT };
 struct PhaseTrace {
-#ifdef STENOS_HOST_TRACE
+	double* acc; // STAGE_COUNT sums in milliseconds (nullptr: none)
 	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-	void mark(const char* what)
+	explicit PhaseTrace(double* sums = nullptr) : acc(sums) {}
+	void mark(const char* what, int stage)
 	{
 		const auto n = std::chrono::steady_clock::now();
-		fprintf(stderr, "[stenos] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+		const double ms = std::chrono::duration<double, std::milli>(n - t).count();
+		if (acc)
+			acc[stage] += ms;
+#ifdef STENOS_HOST_TRACE
+		fprintf(stderr, "[stenos] %-28s %8.2f ms\n", what, ms);
+#else
+		(void)what;
+#endif
 		t = n;
 	}
-#else
-	void mark(const char*) {}
-#endif
 };
 
 inline void put_le(uint8_t* p, uint64_t v, int n)
@@ -226,10 +234,11 @@ struct stenos_context_s {
 	DevBuf tmp1, tmp2;                               // device scratch for superblocks that pass through zstd on the host (codes 3-5)
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
 	DevBuf walk;                                     // segments of the parallel header walk (walk.h)
+	DevBuf dslots, dtab;                             // levels >= 2, device destinations: zstd output slots of two batches and their offset / size tables
 	bool test_serial_walk = false;                   // stenos_hip_test_walk: frames without an index are walked by one lane
 	DevBuf wide;                                     // bytesoftype above 64: scratch of the HBM-resident kernels (kernels_wide.hip)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) unused, [24,32) scan carry, [64,320) override payload
-	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage; // host staging of the strategy layer
+	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage, h_tab; // host staging of the strategy layer
 	uint64_t* h_total = nullptr;                     // pinned copy of misc[0,16) for compress; decode status at +32
 	// last asynchronous job
 	hipStream_t job_stream = nullptr;
@@ -242,6 +251,10 @@ struct stenos_context_s {
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr }; // encode start/stop, decode start/stop
 	bool ev_valid[2] = { false, false };
 	hipStream_t up_stream = nullptr, main_stream = nullptr; // chunked host-pointer calls: uploads / coding + downloads
+	hipStream_t copy_stream = nullptr, upload_stream = nullptr; // levels >= 2: block streams to the host / the frame to the device, beside the host's zstd
+	std::vector<hipEvent_t> batch_ev;   // ... one event per batch of superblocks
+	std::vector<hipEvent_t> set_ev;     // ... and one per set of zstd output slots on their way to the device
+	double stage_ms[16] = { 0 }; // levels >= 2: wall time per stage of the strategy layer, summed over the calls (stenos_hip_stage_ms)
 	int last_devices = 1; // devices the last host-pointer call used
 	int hip_devices = 0;  // stenos_hip_set_devices: devices a host-pointer call may spread over (0: STENOS_HIP_DEVICES, else one)
 	bool test_lanes_share_device = false; // stenos_hip_test_lanes: the lanes all use the current device (one-GPU test boxes)
@@ -260,7 +273,7 @@ struct stenos_context_s {
 
 	void release_device_state()
 	{
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide, &walk };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide, &walk, &dslots, &dtab };
 		for (DevBuf* b : all)
 			b->release();
 		if (h_total)
@@ -272,11 +285,17 @@ struct stenos_context_s {
 				e = nullptr;
 			}
 		ev_valid[0] = ev_valid[1] = false;
-		for (hipStream_t* s : { &up_stream, &main_stream })
+		for (hipStream_t* s : { &up_stream, &main_stream, &copy_stream, &upload_stream })
 			if (*s) {
 				(void)hipStreamDestroy(*s);
 				*s = nullptr;
 			}
+		for (hipEvent_t e : batch_ev)
+			(void)hipEventDestroy(e);
+		batch_ev.clear();
+		for (hipEvent_t e : set_ev)
+			(void)hipEventDestroy(e);
+		set_ev.clear();
 		last_nsb = 0;
 		job_kind = 0;
 	}
@@ -304,10 +323,10 @@ struct stenos_context_s {
 				l->~stenos_context_s();
 				free(l);
 			}
-		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide, &walk };
+		DevBuf* all[] = { &in, &out, &slots, &bsize, &binfo, &bneed, &boff, &sbcsize, &sbneed, &sbcode, &sboff, &misc, &tmp1, &tmp2, &qprod, &shuf, &mid0, &mid1, &chain, &wide, &walk, &dslots, &dtab };
 		for (DevBuf* b : all)
 			b->release();
-		HostBuf* host[] = { &h_in, &h_out, &h_blocks, &h_shuf, &h_mid0, &h_mid1, &h_stage };
+		HostBuf* host[] = { &h_in, &h_out, &h_blocks, &h_shuf, &h_mid0, &h_mid1, &h_stage, &h_tab };
 		for (HostBuf* b : host)
 			b->release();
 		if (h_total)
@@ -315,9 +334,13 @@ struct stenos_context_s {
 		for (hipEvent_t e : ev)
 			if (e)
 				(void)hipEventDestroy(e);
-		for (hipStream_t s : { up_stream, main_stream })
+		for (hipStream_t s : { up_stream, main_stream, copy_stream, upload_stream })
 			if (s)
 				(void)hipStreamDestroy(s);
+		for (hipEvent_t e : batch_ev)
+			(void)hipEventDestroy(e);
+		for (hipEvent_t e : set_ev)
+			(void)hipEventDestroy(e);
 	}
 	void mark(int idx, hipStream_t stream)
 	{
@@ -725,8 +748,9 @@ void parallel_for(uint64_t cnt, const std::function<void(uint64_t)>& fn)
 // scratch buffer), shuffles the input and prepares the plane middles for the LZ4-dry estimates; the host runs
 // the estimator and zstd (third-party entropy coder) and assembles the frame in `h_dst` with the reference's
 // serial capacity semantics.  h_src / d_src: host and device copies of the input.
+// d_dst (device destinations): the frame is uploaded batch by batch while the next batch is in zstd; h_dst is the staging.
 size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint8_t* d_src, size_t T, size_t bytes, uint8_t* h_dst, size_t dst_size,
-			 int level, const FramePlan& f, hipStream_t stream)
+			 int level, const FramePlan& f, hipStream_t stream, uint8_t* d_dst = nullptr)
 {
 	if (!zstd().ok)
 		return STENOS_ERROR_ZSTD_INTERNAL;
@@ -787,7 +811,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	    hipMemcpyAsync(csize.data(), j.sb_csize, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 	    hipMemcpyAsync(qprod.data(), j.qprod, f.nsb * 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	PhaseTrace trace;
+	PhaseTrace trace(ctx->stage_ms);
 	// ... and, for an input that lives on the device (h_src == NULL), the part of it the estimator looks at: the first
 	// 1/16 of every superblock (stenos.cpp:497-499), one strided copy into a host image of the input.  The rest of a
 	// superblock is fetched only if it ends up going through zstd as it is (or as a copy).
@@ -806,7 +830,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	}
 	if (hipStreamSynchronize(stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
-	trace.mark("verdicts and samples to host");
+	trace.mark("verdicts and samples to host", STAGE_GPU_PASS);
 	HostBuf& blocks = ctx->h_blocks;
 	// transposed views for the estimator and the transposed zstd strategies (levels > 2 only, stenos.cpp:515-537)
 	const bool transposed = T > 1 && level > 2;
@@ -824,7 +848,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		    hipMemcpy(mid0.data(), ctx->mid0.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
 		    hipMemcpy(mid1.data(), ctx->mid1.p, bytes, hipMemcpyDeviceToHost) != hipSuccess)
 			return STENOS_ERROR_UNDEFINED;
-		trace.mark("transposed views to host");
+		trace.mark("transposed views to host", STAGE_GPU_PASS);
 	}
 
 	int zstd_level = level; // stenos.cpp:441-460
@@ -923,7 +947,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	// pack nor a transfer.
 	std::vector<int> all_choice(f.nsb);
 	parallel_for(f.nsb, [&](uint64_t s) { all_choice[s] = decide(s); });
-	trace.mark("estimates");
+	trace.mark("estimates", STAGE_ESTIMATES);
 	{
 		std::vector<uint8_t> keep(f.nsb);
 		uint64_t dropped = 0;
@@ -942,9 +966,37 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		const size_t blocks_size = (size_t)sboff[f.nsb];
 		if (!blocks.ensure(blocks_size + 64))
 			return STENOS_ERROR_ALLOC;
-		if (blocks_size && hipMemcpyAsync(blocks.data(), j.dst, blocks_size, hipMemcpyDeviceToHost, stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		if (lazy_src) { // raw bytes of the superblocks that go through zstd as they are (runs of neighbours in one copy)
+		trace.mark("pack", STAGE_GPU_PASS);
+	}
+	// The block streams come to the host batch by batch on a stream of their own, in the order the batches are compressed:
+	// the transfer of batch k + 1 runs while batch k is in zstd (the link moves 50 GB/s, sixteen cores' zstd a quarter of
+	// that), and so does the upload of the finished part of the frame when the destination is device memory.
+	const size_t ample = 4 + f.sb + f.sb / 128 + 1024;
+	uint64_t batch = ((size_t)256 << 20) / f.sb;
+	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
+	const uint64_t nbatch = (f.nsb + batch - 1) / batch;
+	if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+		return STENOS_ERROR_ALLOC;
+	if (d_dst && !ctx->upload_stream && hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking) != hipSuccess)
+		return STENOS_ERROR_ALLOC;
+	hipStream_t copy = ctx->copy_stream;                          // device -> host: block streams, in batch order
+	hipStream_t up = d_dst ? ctx->upload_stream : ctx->copy_stream; // host -> device: the frame (not queued behind the downloads)
+	struct Drain { // (whatever way this function is left, no transfer of this call is still in flight)
+		hipStream_t a, b;
+		~Drain()
+		{
+			(void)hipStreamSynchronize(a);
+			(void)hipStreamSynchronize(b);
+		}
+	} drain = { copy, up };
+	while (ctx->batch_ev.size() < nbatch) {
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+			return STENOS_ERROR_ALLOC;
+		ctx->batch_ev.push_back(e);
+	}
+	{
+		if (lazy_src) { // raw bytes of the superblocks that go through zstd as they are (runs of neighbours in one copy), first
 			uint8_t* img = ctx->h_in.data();
 			for (uint64_t s = 0; s < f.nsb;) {
 				if (all_choice[s] == 1) {
@@ -955,34 +1007,65 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 				while (e < f.nsb && all_choice[e] != 1)
 					++e;
 				const size_t b0 = (size_t)(s * f.sb), b1 = (size_t)(e * f.sb < bytes ? e * f.sb : bytes);
-				if (hipMemcpyAsync(img + b0, d_src + b0, b1 - b0, hipMemcpyDeviceToHost, stream) != hipSuccess)
+				if (hipMemcpyAsync(img + b0, d_src + b0, b1 - b0, hipMemcpyDeviceToHost, copy) != hipSuccess)
 					return STENOS_ERROR_UNDEFINED;
 				s = e;
 			}
 		}
-		if (hipStreamSynchronize(stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		trace.mark("block streams to host");
+		for (uint64_t b = 0; b < nbatch; ++b) {
+			const uint64_t s0 = b * batch, s1 = s0 + batch < f.nsb ? s0 + batch : f.nsb;
+			const size_t lo = (size_t)sboff[s0], hi = (size_t)sboff[s1];
+			if ((hi > lo && hipMemcpyAsync(blocks.data() + lo, j.dst + lo, hi - lo, hipMemcpyDeviceToHost, copy) != hipSuccess) ||
+			    hipEventRecord(ctx->batch_ev[b], copy) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+		}
 	}
 	// zstd's result depends on the capacity only below ZSTD_compressBound of its input, so the superblocks of a
 	// batch are compressed in parallel into roomy scratch buffers and then laid out in order; a superblock that
 	// meets less room than that in the caller's buffer (the end of a tight buffer) is redone with the exact
 	// capacity, as the reference's serial loop would have seen it.
-	const size_t ample = 4 + f.sb + f.sb / 128 + 1024;
-	uint64_t batch = ((size_t)256 << 20) / f.sb;
-	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
+	// Device destinations: the batch's slots go to the device as they are (one transfer, beside the next batch's zstd) and a
+	// kernel puts every superblock at its place in the frame: the host's threads do not touch the bytes again.  Two sets of
+	// slots, so that a batch can be compressed while the one before it is on its way.
 	std::vector<int> choice;
-	if (!ctx->h_stage.ensure((size_t)(batch < f.nsb ? batch : f.nsb) * ample)) // (kept by the context: a fresh 100 MB allocation per call costs more than the zstd calls)
+	const size_t set_slots = (size_t)(batch < f.nsb ? batch : f.nsb) * ample;
+	const int nsets = d_dst ? 2 : 1;
+	if (!ctx->h_stage.ensure((size_t)nsets * set_slots)) // (kept by the context: a fresh 100 MB allocation per call costs more than the zstd calls)
 		return STENOS_ERROR_ALLOC;
+	const size_t tab_bytes = ((size_t)batch * 16 + 63) & ~(size_t)63; // per set: offsets, sizes (uint64 each)
+	if (d_dst && (!ctx->dslots.ensure(2 * set_slots + 64) || !ctx->dtab.ensure(2 * tab_bytes + 64) || !ctx->h_tab.ensure(2 * tab_bytes + 64)))
+		return STENOS_ERROR_ALLOC;
+	while (d_dst && ctx->set_ev.size() < 2) {
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+			return STENOS_ERROR_ALLOC;
+		ctx->set_ev.push_back(e);
+	}
+	bool set_busy[2] = { false, false };
 	struct { uint8_t* p; uint8_t* get() const { return p; } } scratch = { ctx->h_stage.data() };
 	std::vector<size_t> sizes;
 	std::vector<uint64_t> dslot; // position of a choice-4 superblock in the batch's delta buffer
 	std::vector<size_t> offsets;
 	std::vector<uint8_t> deltas;
 	size_t off = f.header;
-	for (uint64_t s0 = 0; s0 < f.nsb; s0 += batch) {
+	auto upload = [&](size_t lo, size_t hi) -> bool { // frame bytes [lo, hi) that the host laid out in h_dst
+		return !d_dst || hi <= lo || hipMemcpyAsync(d_dst + lo, h_dst + lo, hi - lo, hipMemcpyHostToDevice, up) == hipSuccess;
+	};
+	uint64_t nb = 0;
+	for (uint64_t s0 = 0; s0 < f.nsb; s0 += batch, ++nb) {
 		const uint64_t cnt = (s0 + batch < f.nsb ? s0 + batch : f.nsb) - s0;
 		choice.assign(all_choice.begin() + (ptrdiff_t)s0, all_choice.begin() + (ptrdiff_t)(s0 + cnt));
+		const int set = d_dst ? (int)(nb & 1) : 0;
+		scratch.p = ctx->h_stage.data() + (size_t)set * set_slots;
+		if (set_busy[set]) { // the slots of this set are still on their way to the device (two batches ago)
+			if (hipEventSynchronize(ctx->set_ev[(size_t)set]) != hipSuccess)
+				return STENOS_ERROR_UNDEFINED;
+			set_busy[set] = false;
+			trace.mark("slots to device", STAGE_UPLOAD);
+		}
+		if (hipEventSynchronize(ctx->batch_ev[s0 / batch]) != hipSuccess) // the batch's block streams (and the raw superblocks) are on the host
+			return STENOS_ERROR_UNDEFINED;
+		trace.mark("block streams to host", STAGE_BLOCKS_TO_HOST);
 #ifdef STENOS_HOST_TRACE
 		{
 			unsigned h[5] = { 0, 0, 0, 0, 0 };
@@ -1018,7 +1101,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 		parallel_for(cnt, [&](uint64_t k) {
 			sizes[k] = emit(s0 + k, choice[k], deltas.data() + dslot[k] * f.sb, scratch.get() + k * ample, ample);
 		});
-		trace.mark("zstd");
+		trace.mark("zstd", STAGE_ZSTD);
 		// Layout in order.  When even the last superblock of the batch finds ample room (the usual case), the
 		// offsets are a plain prefix sum and the copies run on the worker threads.
 		{
@@ -1030,13 +1113,32 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 				plain = !is_err(sizes[k]) && dst_size >= end + ample;
 				end += plain ? sizes[k] : 0;
 			}
+			if (plain && d_dst) { // laid out on the device
+				uint64_t* tab = (uint64_t*)(ctx->h_tab.data() + (size_t)set * tab_bytes);
+				for (uint64_t k = 0; k < cnt; ++k) {
+					tab[k] = offsets[k];
+					tab[batch + k] = sizes[k];
+				}
+				uint8_t* d_slots = ctx->dslots.as<uint8_t>() + (size_t)set * set_slots;
+				uint64_t* d_tab = (uint64_t*)(ctx->dtab.as<uint8_t>() + (size_t)set * tab_bytes);
+				if (hipMemcpyAsync(d_slots, scratch.get(), (size_t)cnt * ample, hipMemcpyHostToDevice, up) != hipSuccess ||
+				    hipMemcpyAsync(d_tab, tab, (size_t)batch * 16, hipMemcpyHostToDevice, up) != hipSuccess ||
+				    stenos_k_launch_gather_pieces(d_slots, ample, d_tab, d_tab + batch, (uint32_t)cnt, d_dst, up) != hipSuccess ||
+				    hipEventRecord(ctx->set_ev[(size_t)set], up) != hipSuccess)
+					return STENOS_ERROR_UNDEFINED;
+				set_busy[set] = true;
+				off = end;
+				trace.mark("layout", STAGE_LAYOUT);
+				continue;
+			}
 			if (plain) {
 				parallel_for(cnt, [&](uint64_t k) { memcpy(h_dst + offsets[k], scratch.get() + k * ample, sizes[k]); });
 				off = end;
-				trace.mark("layout");
+				trace.mark("layout", STAGE_LAYOUT);
 				continue;
 			}
 		}
+		const size_t batch_begin = off;
 		for (uint64_t k = 0; k < cnt; ++k) {
 			if (dst_size < off + 4) // stenos.cpp:427-429
 				return STENOS_ERROR_DST_OVERFLOW;
@@ -1052,7 +1154,14 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 				return r;
 			off += r;
 		}
-		trace.mark("layout");
+		trace.mark("layout", STAGE_LAYOUT);
+		if (!upload(batch_begin, off)) // (a batch the host laid out itself: the end of a tight destination)
+			return STENOS_ERROR_UNDEFINED;
+	}
+	if (d_dst) { // the frame header last; then everything has to be there
+		if (!upload(0, f.header) || hipStreamSynchronize(up) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		trace.mark("upload", STAGE_UPLOAD);
 	}
 	return off;
 }
@@ -1082,11 +1191,9 @@ size_t compress_device(stenos_context_s* ctx, const void* d_src, size_t T, size_
 		if (!h_out.ensure(cap + 64))
 			return STENOS_ERROR_ALLOC;
 		// (no host copy of the input: the strategy layer fetches what it looks at)
-		size_t r = compress_strategy(ctx, nullptr, (const uint8_t*)d_src, T, bytes, h_out.data(), cap, level, f, stream);
+		size_t r = compress_strategy(ctx, nullptr, (const uint8_t*)d_src, T, bytes, h_out.data(), cap, level, f, stream, (uint8_t*)d_dst);
 		if (is_err(r))
 			return r;
-		if (hipMemcpyAsync(d_dst, h_out.data(), r, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
 		ctx->last_nsb = 0; // no device-side index for these frames
 		ctx->h_total[0] = r;
 		ctx->h_total[1] = 0;
@@ -1171,7 +1278,7 @@ size_t parse_frame(const uint8_t* h, size_t have, size_t T, size_t dst_size, Fra
 size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const uint8_t* h_frame, size_t size, size_t T, const uint64_t* h_index,
 			 const FrameInfo& fi, uint8_t* d_dst, hipStream_t stream)
 {
-	PhaseTrace trace;
+	PhaseTrace trace(ctx->stage_ms);
 	if (!h_frame) {
 		HostBuf& frame_copy = ctx->h_in;
 		if (!frame_copy.ensure(size + 64))
@@ -1210,49 +1317,79 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 		return STENOS_ERROR_ZSTD_INTERNAL;
 
 	// The superblocks are inflated by the worker threads into one staging buffer per batch (slot k: 12 spare bytes,
-	// a [1][size:3] header for code 5, the bytes at +16), moved to the device in one copy and finished there.
+	// a [1][size:3] header for code 5, the bytes at +16), moved to the device in one copy and finished there.  Two sets of
+	// buffers: the device works on one batch while the threads inflate the next.
 	const size_t slot = (((size_t)fi.sb + 64 + 15) & ~(size_t)15) + 16;
 	uint64_t batch = ((size_t)256 << 20) / slot;
 	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
 	if (batch > items.size())
 		batch = items.size();
-	if (!ctx->tmp1.ensure(batch * slot + 64) || !ctx->tmp2.ensure(batch * slot + 64) || !ctx->bsize.ensure(batch * 4 + 64) ||
-	    !ctx->binfo.ensure(batch * 8 + 64) || !ctx->misc.ensure(4096))
+	const size_t set_bytes = (batch * slot + 63) & ~(size_t)63, set_ids = (batch * 4 + 63) & ~(size_t)63, set_idx = (batch * 8 + 63) & ~(size_t)63;
+	if (!ctx->tmp1.ensure(2 * set_bytes + 64) || !ctx->tmp2.ensure(2 * set_bytes + 64) || !ctx->bsize.ensure(2 * set_ids + 64) ||
+	    !ctx->binfo.ensure(2 * set_idx + 64) || !ctx->misc.ensure(4096))
 		return STENOS_ERROR_ALLOC;
-	uint8_t* t1 = ctx->tmp1.as<uint8_t>();
-	uint8_t* t2 = ctx->tmp2.as<uint8_t>();
-	uint32_t* d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 8);
 	HostBuf& stage = ctx->h_stage;
-	if (!stage.ensure(batch * slot + 64))
+	if (!stage.ensure(2 * set_bytes + 64))
 		return STENOS_ERROR_ALLOC;
-	std::vector<uint32_t> ids;
-	std::vector<uint64_t> idx;
-	for (size_t i0 = 0; i0 < items.size(); i0 += batch) {
+	while (ctx->batch_ev.size() < 2) {
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+			return STENOS_ERROR_ALLOC;
+		ctx->batch_ev.push_back(e);
+	}
+	std::vector<uint32_t> ids[2];
+	std::vector<uint64_t> idx[2];
+	volatile uint32_t* h_status = (volatile uint32_t*)((uint8_t*)ctx->h_total + 40); // (page-locked: the device writes it)
+	h_status[0] = h_status[1] = 0;
+	bool pending[2] = { false, false };
+	auto settle = [&](int set) -> size_t { // the batch that used this set of buffers is through
+		if (!pending[set])
+			return 0;
+		pending[set] = false;
+		if (hipEventSynchronize(ctx->batch_ev[(size_t)set]) != hipSuccess)
+			return STENOS_ERROR_UNDEFINED;
+		return h_status[set] ? (size_t)STENOS_ERROR_INVALID_INPUT : 0;
+	};
+	size_t nbatch = 0;
+	for (size_t i0 = 0; i0 < items.size(); i0 += batch, ++nbatch) {
+		const int set = (int)(nbatch & 1);
 		const size_t cnt = items.size() - i0 < batch ? items.size() - i0 : (size_t)batch;
+		if (size_t e = settle(set)) {
+			(void)hipStreamSynchronize(stream);
+			return e;
+		}
+		trace.mark("device finish", STAGE_DEVICE_FINISH);
+		uint8_t* const hs = stage.data() + (size_t)set * set_bytes;
+		uint8_t* const t1 = ctx->tmp1.as<uint8_t>() + (size_t)set * set_bytes;
+		uint8_t* const t2 = ctx->tmp2.as<uint8_t>() + (size_t)set * set_bytes;
+		uint32_t* const d_ids = (uint32_t*)(ctx->bsize.as<uint8_t>() + (size_t)set * set_ids);
+		uint64_t* const d_idx = (uint64_t*)(ctx->binfo.as<uint8_t>() + (size_t)set * set_idx);
+		uint32_t* const d_status = (uint32_t*)(ctx->misc.as<uint8_t>() + 328 + 4 * set);
 		parallel_for(cnt, [&](uint64_t k) {
 			Item& it = items[i0 + k];
 			// code 5: zstd over the block stream, at most the superblock size (stenos.cpp:732)
 			const size_t cap = it.code == 5 ? (size_t)fi.sb + 64 : it.dsize;
-			it.r = zstd().decompress(stage.data() + k * slot + 16, cap, h_frame + h_index[it.s] + 4, it.csize);
+			it.r = zstd().decompress(hs + k * slot + 16, cap, h_frame + h_index[it.s] + 4, it.csize);
 		});
-		trace.mark("zstd inflate");
-		ids.clear();
-		idx.clear();
+		trace.mark("zstd inflate", STAGE_INFLATE);
+		ids[set].clear();
+		idx[set].clear();
 		for (size_t k = 0; k < cnt; ++k) {
 			const Item& it = items[i0 + k];
-			if (zstd().is_error(it.r) || (it.code != 5 && it.code != 2 && it.r != it.dsize)) // stenos.cpp:696-698, 706-708, 718-720
+			if (zstd().is_error(it.r) || (it.code != 5 && it.code != 2 && it.r != it.dsize)) { // stenos.cpp:696-698, 706-708, 718-720
+				(void)hipStreamSynchronize(stream);
 				return STENOS_ERROR_INVALID_INPUT;
+			}
 			if (it.code == 5) { // -> one BLOCK superblock for the block decoder (stenos.cpp:726-740)
-				uint8_t* h4 = stage.data() + k * slot + 12;
+				uint8_t* h4 = hs + k * slot + 12;
 				h4[0] = 1;
 				put_le(h4 + 1, it.r, 3);
-				ids.push_back((uint32_t)it.s);
-				idx.push_back(k * slot + 12);
+				ids[set].push_back((uint32_t)it.s);
+				idx[set].push_back(k * slot + 12);
 			}
 		}
-		if (hipMemcpyAsync(t1, stage.data(), cnt * slot, hipMemcpyHostToDevice, stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
-		for (size_t k = 0; k < cnt; ++k) {
+		bool ok = hipMemcpyAsync(t1, hs, cnt * slot, hipMemcpyHostToDevice, stream) == hipSuccess;
+		for (size_t k = 0; k < cnt && ok; ++k) {
 			const Item& it = items[i0 + k];
 			uint8_t* out = d_dst + it.s * (uint64_t)fi.sb;
 			const uint8_t* in = t1 + k * slot + 16;
@@ -1266,37 +1403,39 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 				if (e == hipSuccess)
 					e = stenos_k_launch_shuffle(t2 + k * slot, out, (uint32_t)T, it.dsize, true, stream);
 			}
-			if (e != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
+			ok = e == hipSuccess;
 		}
-		uint32_t status = 0;
-		if (!ids.empty()) {
-			if (hipMemcpyAsync(ctx->bsize.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
-			    hipMemcpyAsync(ctx->binfo.p, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, stream) != hipSuccess ||
-			    hipMemsetAsync(d_status, 0, 4, stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
+		if (ok && !ids[set].empty()) {
+			ok = hipMemcpyAsync(d_ids, ids[set].data(), ids[set].size() * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
+			     hipMemcpyAsync(d_idx, idx[set].data(), idx[set].size() * 8, hipMemcpyHostToDevice, stream) == hipSuccess &&
+			     hipMemsetAsync(d_status, 0, 4, stream) == hipSuccess;
 			DecodeArgs a;
 			a.frame = t1;
 			a.size = cnt * slot;
-			a.sb_off = ctx->binfo.as<uint64_t>();
-			a.sb_ids = ctx->bsize.as<uint32_t>();
+			a.sb_off = d_idx;
+			a.sb_ids = d_ids;
 			a.dst = d_dst;
 			a.total_bytes = fi.total;
-			a.nsb = ids.size();
+			a.nsb = ids[set].size();
 			a.sb_bytes = (uint32_t)fi.sb;
 			a.T = (uint32_t)T;
 			a.status = d_status;
-			if (!wide_scratch(ctx, T, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes))
-				return STENOS_ERROR_ALLOC;
-			if (stenos_k_launch_decode(a, stream) != hipSuccess || hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
-				return STENOS_ERROR_UNDEFINED;
+			ok = ok && wide_scratch(ctx, T, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes) && stenos_k_launch_decode(a, stream) == hipSuccess &&
+			     hipMemcpyAsync((void*)(h_status + set), d_status, 4, hipMemcpyDeviceToHost, stream) == hipSuccess;
 		}
-		if (hipStreamSynchronize(stream) != hipSuccess) // the staging buffers are reused by the next batch
+		ok = ok && hipEventRecord(ctx->batch_ev[(size_t)set], stream) == hipSuccess;
+		if (!ok) {
+			(void)hipStreamSynchronize(stream);
 			return STENOS_ERROR_UNDEFINED;
-		if (status)
-			return STENOS_ERROR_INVALID_INPUT;
-		trace.mark("device finish");
+		}
+		pending[set] = true;
 	}
+	for (int set = 0; set < 2; ++set)
+		if (size_t e = settle(set)) {
+			(void)hipStreamSynchronize(stream);
+			return e;
+		}
+	trace.mark("device finish", STAGE_DEVICE_FINISH);
 	return 0;
 }
 
@@ -2329,6 +2468,18 @@ void stenos_hip_set_devices(stenos_context* ctx, int devices)
 {
 	if (ctx)
 		ctx->hip_devices = devices > 0 ? devices : 0;
+}
+int stenos_hip_stage_ms(stenos_context* ctx, double* out, int n, int reset)
+{
+	if (!ctx)
+		return 0;
+	const int k = n < (int)STAGE_COUNT ? n : (int)STAGE_COUNT;
+	for (int i = 0; i < k && out; ++i)
+		out[i] = ctx->stage_ms[i];
+	if (reset)
+		for (double& v : ctx->stage_ms)
+			v = 0;
+	return (int)STAGE_COUNT;
 }
 void stenos_hip_test_walk(stenos_context* ctx, int serial)
 {

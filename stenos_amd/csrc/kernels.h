@@ -61,6 +61,7 @@ bool stenos_k_fused_supported(uint32_t T);
 uint32_t stenos_k_fused_groups(uint64_t nsb);
 size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb);
 hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t bytes, bool inverse, hipStream_t stream);
+hipError_t stenos_k_launch_gather_pieces(const uint8_t* src, uint64_t stride, const uint64_t* off, const uint64_t* size, uint32_t count, uint8_t* dst, hipStream_t stream);
 hipError_t stenos_k_launch_shuffle_superblocks(const uint8_t* src, uint8_t* dst, uint32_t T, uint64_t sb, uint64_t total, hipStream_t stream);
 hipError_t stenos_k_launch_delta_middles(const uint8_t* shuffled, uint8_t* out, uint32_t T, uint64_t sb, uint64_t total, uint32_t level, bool with_delta,
 					 hipStream_t stream);

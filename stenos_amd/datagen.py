@@ -155,7 +155,7 @@ def splitmix64_torch(seed: int, n: int, device, start: int = 0):
 
 def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25, start: int = 0):
     """Flat uint8 CUDA tensor holding elements [start, start + n) of the sequence `kind` (T bytes each);
-    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine."""
+    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine, smooth8."""
     import torch
 
     out = torch.empty(n * T, dtype=torch.uint8, device=device)
@@ -186,6 +186,13 @@ def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chu
         elif kind == "sine":
             x = torch.sin(torch.arange(s, s + m, dtype=torch.float64, device=device) * 0.001)
             v = x if T == 8 else x.to(torch.float32)
+        elif kind == "smooth8":  # (the device's sin: the same signal as generate(), not bit for bit the same bytes)
+            assert T == 1
+            u = splitmix64_torch(seed, m, device, start=s)
+            lo, hi = u & 0xFFFFFFFF, _lsr(u, 32)
+            noise = (hi * 1 + lo) % 5 - 2  # u mod 5 of the unsigned value: 2^32 mod 5 = 1
+            x = (128 + 100 * torch.sin(0.01 * torch.arange(s, s + m, dtype=torch.float64, device=device))).to(torch.int64) + noise
+            v = (x & 0xFF).to(torch.uint8)
         else:
             raise ValueError(kind)
         out[s0 * T:(s0 + m) * T] = v.contiguous().view(torch.uint8).reshape(-1)
