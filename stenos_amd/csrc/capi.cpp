@@ -255,6 +255,7 @@ struct stenos_context_s {
 	std::vector<hipEvent_t> batch_ev;   // ... one event per batch of superblocks
 	std::vector<hipEvent_t> set_ev;     // ... and one per set of zstd output slots on their way to the device
 	double stage_ms[16] = { 0 }; // levels >= 2: wall time per stage of the strategy layer, summed over the calls (stenos_hip_stage_ms)
+	bool warm = false;    // a device call has gone through on this context (buffers, code objects and streams are up)
 	int last_devices = 1; // devices the last host-pointer call used
 	int hip_devices = 0;  // stenos_hip_set_devices: devices a host-pointer call may spread over (0: STENOS_HIP_DEVICES, else one)
 	bool test_lanes_share_device = false; // stenos_hip_test_lanes: the lanes all use the current device (one-GPU test boxes)
@@ -303,9 +304,14 @@ struct stenos_context_s {
 	{
 		int cur = -1;
 		if (probed && usable && hipGetDevice(&cur) == hipSuccess && cur != device) {
-			// the caller switched devices between calls: buffers of the old device are of no use on this one
+			// the caller switched devices between calls: buffers of the old device are of no use on this one.  An asynchronous
+			// job that is still pending there is waited for first (its stream outlives the switch); its result is lost to
+			// stenos_hip_finish, which then reports that there is no job -- not a silent success.
+			if (job_kind && job_stream)
+				(void)hipStreamSynchronize(job_stream);
 			release_device_state();
 			probed = false;
+			warm = false;
 		}
 		if (!probed) {
 			probed = true;
@@ -1989,7 +1995,7 @@ size_t compress_timed(stenos_context* ctx, const uint8_t* src, size_t T, size_t 
 		const double rest = (double)(bytes - pos - n) / rate[0]; // what copying everything behind this slice takes
 		// the first device call of a context also pays for the runtime's start, the code object and the buffers: a tight
 		// budget on a cold context is better spent copying
-		const double cold = ctx->in.cap == 0 && ctx->slots.cap == 0 ? 0.25 : 0.0;
+		const double cold = ctx->warm ? 0.0 : 0.25;
 		int level = 0;
 		if (top >= 1 && left > 0 && (double)n / rate[1] + rest + cold <= left)
 			level = 1;
@@ -2091,7 +2097,9 @@ size_t stenos_compress_generic(stenos_context* ctx, const void* src, size_t byte
 		// page-locked caller memory: no staging on that side (both sides: no copy at all)
 		void* a_src = device_alias(src, bytes);
 		void* a_dst = device_alias(dst, dst_size);
-		if (a_src || a_dst) {
+		// (one side only and a large call: the chunked path below overlaps its upload, coding and download, which a single
+		// pass with a blocking copy on the other side would not)
+		if ((a_src && a_dst) || ((a_src || a_dst) && bytes < kHostChunkedFrom)) {
 			const size_t cap = dst_size < worst ? dst_size : worst;
 			if ((!a_src && !ctx->in.ensure(bytes + 64)) || (!a_dst && !ctx->out.ensure(cap + 64)))
 				return STENOS_ERROR_ALLOC;
@@ -2199,7 +2207,7 @@ size_t stenos_decompress_generic(stenos_context* ctx, const void* src, size_t by
 	if (!host_codes) {
 		void* a_src = device_alias(src, size);
 		void* a_dst = device_alias(dst, (size_t)fi.total);
-		if (a_src || a_dst) {
+		if ((a_src && a_dst) || ((a_src || a_dst) && fi.total < kHostChunkedFrom)) { // (one side only and large: the chunked path overlaps)
 			if ((!a_src && !ctx->in.ensure(size + 64)) || (!a_dst && !ctx->out.ensure((size_t)fi.total + 64)) || !ctx->sboff.ensure((fi.nsb + 2) * 8))
 				return STENOS_ERROR_ALLOC;
 			if ((!a_src && hipMemcpy(ctx->in.p, src, size, hipMemcpyHostToDevice) != hipSuccess) ||
@@ -2557,6 +2565,7 @@ size_t finish_job(stenos_context_s* ctx)
 		return STENOS_ERROR_INVALID_PARAMETER;
 	if (hipStreamSynchronize(ctx->job_stream) != hipSuccess)
 		return STENOS_ERROR_UNDEFINED;
+	ctx->warm = true;
 	const int kind = ctx->job_kind;
 	ctx->job_kind = 0;
 	if (kind == 1) {
