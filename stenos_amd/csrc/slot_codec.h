@@ -149,18 +149,15 @@ WV_FN U32 biased_sub(const U32& a, const U32& p)
 // (hi << 8) | (lo >> 24): the dword that starts one byte before hi
 WV_FN U32 prev_bytes(const U32& hi, const U32& lo) { return (hi << 8) | (lo >> 24); }
 
-// number of non-zero bytes among the 16 bytes x[0..3]
+// number of non-zero bytes among the 16 bytes x[0..3]: bit 7 of every byte says "not zero", and a dot product with ones adds
+// the sixteen flags up (four v_dot4_u32_u8 instead of merging the flags of the four dwords into one for a population count)
 WV_FN U32 count_nonzero16(const U32* x)
 {
 	const U32 M(0x7f7f7f7fu);
-	U32 t[4];
+	U32 acc(0u);
 	for (int k = 0; k < 4; ++k)
-		t[k] = ((x[k] & M) + M) | x[k]; // bit 7 of every byte: the byte is not zero
-	U32 f = t[3] & 0x80808080u;
-	f = ((t[2] >> 1) & 0x40404040u) | f;
-	f = ((t[1] >> 2) & 0x20202020u) | f;
-	f = ((t[0] >> 3) & 0x10101010u) | f;
-	return popc(f);
+		acc = dot4_u8((((x[k] & M) + M) | x[k]) & 0x80808080u, 0x01010101u, acc);
+	return acc >> 7;
 }
 // smallest and largest of the 16 bytes s[0..3] (unsigned).  A 16-bit minimum has the smallest high byte, so odd bytes are
 // compared where they are and even bytes after a shift by 8 (whatever follows them in the low byte does not matter).
@@ -297,25 +294,52 @@ WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T, con
 }
 
 // OR a value that cannot straddle a dword (a nibble at a nibble-aligned bit position, a byte at a byte-aligned one) into the
-// zeroed image.  Lanes that have nothing to write OR a zero into a dword of their own (`own`, a byte offset: one shared
-// address would serialise the wave in the LDS atomic unit).
-WV_FN void put_small(Lds out, const U32& bitpos, const U32& value, const Pred& p, const U32& own)
+// zeroed image.  Lanes that have nothing to write OR what they computed into a dword of their own OUTSIDE the image (`dump`,
+// a byte offset from the image: the slot area, whose rows are in registers by then) -- one shared address would serialise
+// the wave in the LDS atomic unit, and a place inside the image would have the value masked to zero first.
+WV_FN void put_small(Lds out, const U32& bitpos, const U32& value, const Pred& p, const U32& dump)
 {
-	lds_or32_all(out, sel(p, (bitpos >> 3) & ~3u, own), sel(p, value << (bitpos & 31u), U32(0u)));
+	lds_or32_all(out, sel(p, (bitpos >> 3) & ~3u, dump), value << (bitpos & 31u));
 }
 // the same for up to 32 bits at any bit position
-WV_FN void put_bits(Lds out, const U32& bitpos, const U32& value, const Pred& p, const U32& own)
+WV_FN void put_bits(Lds out, const U32& bitpos, const U32& value, const Pred& p, const U32& dump)
 {
-	const U32 a = sel(p, (bitpos >> 3) & ~3u, own), sh = bitpos & 31u, v = sel(p, value, U32(0u));
-	lds_or32_all(out, a, v << sh);
-	lds_or32_all(out, a + 4u, sel(sh == U32(0u), U32(0u), v >> (U32(32u) - sh)));
+	const U32 a = sel(p, (bitpos >> 3) & ~3u, dump), sh = bitpos & 31u;
+	lds_or32_all(out, a, value << sh);
+	lds_or32_all(out, a + 4u, sel(sh == U32(0u), U32(0u), value >> (U32(32u) - sh)));
 }
 
-// four values of at most `bits` bits, one per byte of x -> 4*bits bits
+// four values of at most `bits` bits (0..8), one per byte of x -> 4*bits bits; the even and the odd bytes are pulled apart
+// with one v_perm_b32 each (0x0c selects a zero byte)
 WV_FN U32 pack4v(const U32& x, const U32& bits)
 {
-	const U32 t = (x & 0x00FF00FFu) | (((x >> 8) & 0x00FF00FFu) << bits);
+	const U32 t = perm_bytes(x, x, 0x0c020c00u) | (perm_bytes(x, x, 0x0c030c01u) << bits);
 	return (t & 0xFFFFu) | ((t >> 16) << (bits + bits));
+}
+
+// The payload of the lane's row (block_compress.h:562-602, 649-664): bit-packed rows as two halves of 8 values, `bits` bytes
+// each, value - minimum on biased bytes; raw rows -- the rows of RAW planes and rows with header 15 -- are the same thing
+// with 8 bits, no minimum and the bytes as they came.  Lanes that write nothing (run-length rows, rows of 0 bits, unused
+// slots) OR whatever they computed into a dump behind the image (the slot area: its rows are in registers by now), so
+// nothing has to be masked to zero for them.
+WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const Pred& rawrow, const Pred& packed, const U32& bits, const U32& rbase)
+{
+	const U32 lane = lane_id();
+	const U32 H(0x80808080u);
+	const Pred usedelta = R.hdr >= U32(8u);
+	const U32 mins = splat_byte0(R.minb);
+	const U32 ebits = sel(rawrow, U32(8u), bits);
+	U32 pk[4];
+	for (int k = 0; k < 4; ++k)
+		pk[k] = pack4v(sel(rawrow, R.sb[k] ^ H, sel(usedelta, R.sd[k], R.sb[k]) - mins), ebits);
+	const U32 sh4 = ebits << 2; // (32 for raw rows: the second dword of a half is pk[1] as it is)
+	U32 s0lo, s0hi, s1lo, s1hi;
+	shl64(pk[1], sh4, s0lo, s0hi);
+	shl64(pk[3], sh4, s1lo, s1hi);
+	const U32 dump = U32(slot2_area(L) - L.out) + lane * 16u;
+	const Pred anyw = rawrow | packed;
+	lds_put_bytes8(out, sel(anyw, rbase, dump), s0lo | pk[0], s0hi);
+	lds_put_bytes8(out, sel(anyw, rbase + ebits, dump), s1lo | pk[2], s1hi);
 }
 
 // Write the blocks of the batch into the zeroed image, block i at byte base[i]: type nibbles, SAME bytes, row headers,
@@ -327,7 +351,7 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	const U32 H(0x80808080u);
 	Lds out = lds + L.out;
 	const uint32_t hs = header_bytes(T);
-	const U32 own = lane * 4u; // where lanes with nothing to write OR their zeros
+	const U32 own = U32(slot2_area(L) - L.out) + lane * 16u; // where lanes with nothing to write OR what they have (outside the image)
 	WV_MARK("emit_nibbles");
 	const U32 bbase = sel(P.second, U32(base1), U32(base0));
 	const U32 pbase = bbase + P.pbase;
@@ -371,26 +395,13 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
 	const Pred rle = normal & isr;
 	const U32 rbase = pbase + sel(israw, r * 16u, R.poff);
-	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each; value - minimum on biased bytes
-	const Pred usedelta = hdr >= U32(8u);
-	const U32 mins = splat_byte0(R.minb);
-	U32 pk[4];
-	for (int k = 0; k < 4; ++k)
-		pk[k] = pack4v(sel(usedelta, R.sd[k], R.sb[k]) - mins, bits);
-	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
-	const Pred anyw = rawrow | packed;
-	const U32 s0lo = sel(rawrow, R.sb[0] ^ H, sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
-	const U32 s0hi = sel(rawrow, R.sb[1] ^ H, sel(packed, pk[1] >> ish4, U32(0u)));
-	const U32 s1lo = sel(rawrow, R.sb[2] ^ H, sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
-	const U32 s1hi = sel(rawrow, R.sb[3] ^ H, sel(packed, pk[3] >> ish4, U32(0u)));
-	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
-	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
+	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
 		const Pred is7 = hdr == U32(7u);
 		// table of the 16 v_perm_b32 selectors that move the bytes whose flag is 0 to the low end (lane f writes entry f;
-		// the slot area is free once the rows are in registers)
-		const uint32_t lut = slot2_area(L);
+		// the row table of the plane-group path is not used here)
+		const uint32_t lut = L.rowinfo; // (free on this path; the slot area takes what idle lanes OR away, see put_small)
 		{
 			U32 pat(0x0c0c0c0cu), at(0u);
 			for (uint32_t k = 0; k < 4; ++k) {
@@ -482,7 +493,7 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 	const U32 H(0x80808080u);
 	Lds out = lds + L.out;
 	const uint32_t hs = header_bytes(T);
-	const U32 own = lane * 4u; // where lanes with nothing to write OR their zeros
+	const U32 own = U32(slot2_area(L) - L.out) + lane * 16u; // where lanes with nothing to write OR what they have (outside the image)
 	WV_MARK("emit_nibbles");
 	const U32 pbase = bbase + P.pbase;
 	{
@@ -533,26 +544,13 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
 	const Pred rle = normal & isr;
 	const U32 rbase = pbase + sel(israw, r * 16u, R.poff);
-	// bit-packed rows (:562-602, 649-664): two halves of 8 values, `bits` bytes each; value - minimum on biased bytes
-	const Pred usedelta = hdr >= U32(8u);
-	const U32 mins = splat_byte0(R.minb);
-	U32 pk[4];
-	for (int k = 0; k < 4; ++k)
-		pk[k] = pack4v(sel(usedelta, R.sd[k], R.sb[k]) - mins, bits);
-	const U32 sh4 = bits << 2, ish4 = U32(32u) - sh4;
-	const Pred anyw = rawrow | packed;
-	const U32 s0lo = sel(rawrow, R.sb[0] ^ H, sel(packed, pk[0] | (pk[1] << sh4), U32(0u)));
-	const U32 s0hi = sel(rawrow, R.sb[1] ^ H, sel(packed, pk[1] >> ish4, U32(0u)));
-	const U32 s1lo = sel(rawrow, R.sb[2] ^ H, sel(packed, pk[2] | (pk[3] << sh4), U32(0u)));
-	const U32 s1hi = sel(rawrow, R.sb[3] ^ H, sel(packed, pk[3] >> ish4, U32(0u)));
-	lds_put_bytes8(out, sel(anyw, rbase, own), s0lo, s0hi);
-	lds_put_bytes8(out, sel(anyw, rbase + sel(rawrow, U32(8u), bits), own), s1lo, s1hi);
+	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
 		const Pred is7 = hdr == U32(7u);
 		// table of the 16 v_perm_b32 selectors that move the bytes whose flag is 0 to the low end (lane f writes entry f;
-		// the slot area is free once the rows are in registers)
-		const uint32_t lut = slot2_area(L);
+		// the row table of the plane-group path is not used here)
+		const uint32_t lut = L.rowinfo; // (free on this path; the slot area takes what idle lanes OR away, see put_small)
 		{
 			U32 pat(0x0c0c0c0cu), at(0u);
 			for (uint32_t k = 0; k < 4; ++k) {

@@ -238,6 +238,15 @@ WV_FN uint64_t ballot(const Pred& p)
 	return m;
 }
 WV_FN uint32_t readlane(const U32& a, uint32_t lane) { return a.l[lane & 63]; }
+// {hi, lo} = (64-bit) x << sh, sh in 0..32
+WV_FN void shl64(const U32& x, const U32& sh, U32& lo, U32& hi)
+{
+	for (int i = 0; i < WAVE; ++i) {
+		const uint64_t v = (uint64_t)x.l[i] << sh.l[i];
+		lo.l[i] = (uint32_t)v;
+		hi.l[i] = (uint32_t)(v >> 32);
+	}
+}
 // bit r of lane 16k + q: p in lane 16k + r (the ballot of the lane's own group of 16 lanes)
 WV_FN U32 row_ballot16(const Pred& p)
 {
@@ -550,6 +559,13 @@ WV_FN U32 funnel_shr(U32 hi, U32 lo, U32 sh) { return __builtin_amdgcn_alignbit(
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN U32 perm_bytes_v(U32 hi, U32 lo, U32 selw) { return __builtin_amdgcn_perm(hi, lo, selw); }
 WV_FN uint64_t ballot(Pred p) { return __builtin_amdgcn_ballot_w64(p); }
+// {hi, lo} = (64-bit) x << sh, sh in 0..32: one v_lshlrev_b64
+WV_FN void shl64(U32 x, U32 sh, U32& lo, U32& hi)
+{
+	const uint64_t v = (uint64_t)x << sh;
+	lo = (U32)v;
+	hi = (U32)(v >> 32);
+}
 // bit r of lane 16k + q: p in lane 16k + r (the ballot of the lane's own group of 16 lanes): one 64-bit shift by a per-lane amount
 WV_FN U32 row_ballot16(Pred p) { return (U32)(__builtin_amdgcn_ballot_w64(p) >> (lane_id_plain() & 48u)) & 0xFFFFu; }
 WV_FN uint32_t readlane(U32 a, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)a, (int)lane); }

@@ -9,6 +9,10 @@ src="$here/stenos_amd/csrc"
 objs=/tmp/w/objs
 mkdir -p "$here/stenos_amd/lib/exp" $objs
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off"
+# the cached objects go when one of their sources is newer
+for f in "$src"/capi.cpp "$src"/strategy.cpp "$src"/decode_kernels.hip "$src"/kernels_wide.hip "$src"/byte_kernels.hip "$src"/walk_kernels.hip "$src"/*.h "$here"/include/*.h; do
+  if [ -f $objs/capi.o ] && [ "$f" -nt $objs/capi.o ] && [ "${f##*/}" != "slot_codec.h" ] && [ "${f##*/}" != "superblock_codec.h" ] && [ -z "$KEEP_OBJS" ]; then rm -f $objs/*.o; fi
+done
 if [ ! -f $objs/capi.o ]; then
   hipcc $flags -mllvm -structurizecfg-skip-uniform-regions=1 -c "$src/decode_kernels.hip" -o $objs/decode_kernels.o 2>/dev/null &
   for f in kernels_wide byte_kernels walk_kernels; do hipcc $flags -DWV_PREDICATE_BRANCHES -c "$src/$f.hip" -o $objs/$f.o 2>/dev/null & done
