@@ -178,12 +178,17 @@ WV_FN U32 bitlen8(const U32& v) { return bitlen((v << 1) | 1u) - 1u; }
 struct SlotRows {
 	U32 sb[4];  // the row's 16 bytes, biased
 	U32 sd[4];  // their deltas against the previous byte in plane order (0 before the plane, block_compress.h:399-401), biased
-	U32 hdr;    // row header nibble (:497-503)
-	U32 minb;   // the row's minimum (of the bytes or of the deltas, whichever the row codes), biased
-	U32 poff;   // offset of the row's payload in the plane
-	U32 minpos; // offset of the row's minimum in the plane, when it has one
+	U32 hm;     // row header nibble (:497-503) | the row's minimum (of the bytes or of the deltas, whichever the row codes), biased, << 8
+	U32 pm;     // offset of the row's payload in the plane (low half) and of its minimum, when it has one (high half): one register
+	            // between the analysis and the emission, where they are scarce
 	Pred emitmin, eq; // the row writes a minimum; its minimum equals that of the row above (bit of the mins-rle mask)
-	U32 type, size;   // of the slot's plane (the same in its 16 lanes)
+	U32 ts;           // size | type << 16 of the slot's plane (the same in its 16 lanes)
+	// (pairs in one register each: between the analysis and the emission the row's 16 bytes, their deltas and the placement are
+	// all alive, and what does not fit goes to scratch memory)
+	WV_MFN U32 hdr() const { return hm & 0xFFu; }
+	WV_MFN U32 minb() const { return hm >> 8; }
+	WV_MFN U32 type() const { return ts >> 16; }
+	WV_MFN U32 size() const { return ts & 0xFFFFu; }
 };
 
 // Analyse the four slots as full-block planes (rle enabled, raw above 256 bytes: block_compress.h:1110-1111, 1190, 1200-1204).
@@ -228,7 +233,7 @@ WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
 	b1 = sel(b1 >= U32(7u), U32(8u), b1);
 	const U32 bits = umin(b0, b1);
 	const Pred type0 = b0 == bits; // ties go to frame-of-reference (:423-427)
-	R.minb = sel(type0, mn, dmn);
+	const U32 minb = sel(type0, mn, dmn);
 	U32 cost = bits * 2u + 1u - (bits >> 3); // (:433-435)
 	U32 hdr = sel(type0, b0 + (b0 >> 3) * 7u, b1 + 8u); // (:497-503)
 	const Pred u1 = c1 < cost; // strictly smaller wins
@@ -237,9 +242,9 @@ WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
 	const Pred u2 = c2 < cost;
 	cost = sel(u2, c2, cost);
 	hdr = sel(u2, U32(6u), hdr);
-	R.hdr = hdr;
+	R.hm = hdr | (minb << 8);
 	const Pred nomin = (hdr == U32(15u)) | ((hdr & 14u) == U32(6u));
-	R.eq = R.minb == row_shr(R.minb, 1, 0x80u); // the minimum before row 0 counts as 0 (:483)
+	R.eq = minb == row_shr(minb, 1, 0x80u); // the minimum before row 0 counts as 0 (:483)
 	const U32 tot = row_add(cost | sel(nomin, U32(1u << 12), U32(0u)) | sel(R.eq, U32(1u << 17), U32(0u)));
 	const U32 sumcost = tot & 0xFFFu, count8 = (tot >> 12) & 31u, eqc = (tot >> 17) & 31u;
 	// mins rle (:478-490): 2 + non-repeated mins < mins that would be written
@@ -248,13 +253,11 @@ WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
 	const U32 minslen = umin(packed, plain);
 	U32 size = sumcost + 8u + minslen - plain; // (:476, 488)
 	const Pred raw = size > U32(256u);
-	R.type = sel(raw, U32(PLANE_RAW), sel(minsrle, U32(PLANE_NORMAL_RLE), U32(PLANE_NORMAL)));
-	R.size = sel(raw, U32(256u), size);
+	R.ts = sel(raw, U32(256u | (PLANE_RAW << 16)), size | sel(minsrle, U32(PLANE_NORMAL_RLE << 16), U32(PLANE_NORMAL << 16)));
 	const U32 pay = cost - sel(nomin, U32(0u), U32(1u));
 	R.emitmin = (minsrle & !R.eq) | (!minsrle & !nomin);
 	const U32 ex = row_excl_scan(pay | sel(R.emitmin, U32(1u << 16), U32(0u)));
-	R.poff = minslen + 8u + (ex & 0xFFFFu);
-	R.minpos = sel(minsrle, U32(10u), U32(8u)) + (ex >> 16);
+	R.pm = ex + (minslen + 8u + sel(minsrle, U32(10u << 16), U32(8u << 16))); // (both halves stay far below 2^16)
 }
 
 // A batch: one block or two consecutive ones whose non-constant planes fill slots 0 .. nslots-1 (block 0 first).
@@ -281,7 +284,7 @@ WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T, con
 	P.valid = (e & 8u) != U32(0u);
 	P.second = (e & 4u) != U32(0u);
 	// inclusive sums of the plane sizes over the slots (the value of a slot is the same in its 16 lanes)
-	U32 incl = R.size + scan_source(R.size, 4, 0u);
+	U32 incl = R.size() + scan_source(R.size(), 4, 0u);
 	incl = incl + scan_source(incl, 5, 0u);
 	const uint32_t p0 = B.nact0 ? readlane(incl, 16u * B.nact0 - 1u) : 0u;
 	const uint32_t pt = B.nslots ? readlane(incl, 16u * B.nslots - 1u) : 0u;
@@ -289,7 +292,7 @@ WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T, con
 	B.full[1] = B.nblk > 1 ? pt - p0 + (T - (B.nslots - B.nact0)) : 0u;
 	P.first = sel(P.second, U32(B.first[1]), U32(B.first[0]));
 	// planes before mine in my block: SAME ones take a byte each (k - j of them), the others are the slots before mine
-	P.pbase = U32(header_bytes(T)) + ((e >> 4) & 3u) + (incl - R.size - sel(P.second, U32(p0), U32(0u)));
+	P.pbase = U32(header_bytes(T)) + ((e >> 4) & 3u) + (incl - R.size() - sel(P.second, U32(p0), U32(0u)));
 	return P;
 }
 
@@ -326,8 +329,8 @@ WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const P
 {
 	const U32 lane = lane_id();
 	const U32 H(0x80808080u);
-	const Pred usedelta = R.hdr >= U32(8u);
-	const U32 mins = splat_byte0(R.minb);
+	const Pred usedelta = R.hdr() >= U32(8u);
+	const U32 mins = splat_byte0(R.minb());
 	const U32 ebits = sel(rawrow, U32(8u), bits);
 	U32 pk[4];
 	for (int k = 0; k < 4; ++k)
@@ -361,9 +364,9 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 		// front of it (:747-750).  Bit position: the table's constant from the block's start or from the end of the plane.
 		const U32 role = (P.e >> 6) & 3u;
 		const U32 byte = (P.first >> ((P.e >> 8) & 31u)) & 0xFFu;
-		const U32 from = sel(role == U32(2u), pbase + R.size, bbase);
+		const U32 from = sel(role == U32(2u), pbase + R.size(), bbase);
 		const Pred nib = role == U32(1u);
-		put_small(out, from * 8u + ((P.e >> 13) & 63u), sel(nib, R.type, byte), role != U32(0u), own);
+		put_small(out, from * 8u + ((P.e >> 13) & 63u), sel(nib, R.type(), byte), role != U32(0u), own);
 	}
 	for (uint32_t i = 0; i < B.nblk; ++i) // a block without a slot: its SAME bytes (the type nibbles are all 0)
 		if (B.act[i] == 0) {
@@ -375,14 +378,14 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 		return;
 	}
 	WV_MARK("emit_rowlanes");
-	const U32 hdr = R.hdr;
-	const Pred israw = P.valid & (R.type == U32(PLANE_RAW));
+	const U32 hdr = R.hdr();
+	const Pred israw = P.valid & (R.type() == U32(PLANE_RAW));
 	const Pred normal = P.valid & !israw;
 	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
-	put_small(out, (pbase + R.minpos) * 8u, R.minb ^ 0x80u, normal & R.emitmin, own);
+	put_small(out, (pbase + (R.pm >> 16)) * 8u, R.minb() ^ 0x80u, normal & R.emitmin, own);
 	{
 		// mins rle mask (:765): bit r = min equals previous min
-		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
+		const Pred isnrle = normal & (R.type() == U32(PLANE_NORMAL_RLE));
 		if (any(isnrle)) {
 			const U32 m16 = row_ballot16(R.eq);
 			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
@@ -394,7 +397,7 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	const Pred rawrow = israw | (normal & is15);
 	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
 	const Pred rle = normal & isr;
-	const U32 rbase = pbase + sel(israw, r * 16u, R.poff);
+	const U32 rbase = pbase + sel(israw, r * 16u, R.pm & 0xFFFFu);
 	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
@@ -463,7 +466,7 @@ WV_FN SlotPlace4 slot_rows_place4(const SlotRows& R, SlotBatch4& B, uint32_t T, 
 	P.blk = posv >> 2;
 	P.valid = s < U32(B.nslots);
 	// every block has at most one slot: its plane's size is the block's plane sum
-	const uint32_t z0 = readlane(R.size, 0), z1 = readlane(R.size, 16), z2 = readlane(R.size, 32), z3 = readlane(R.size, 48);
+	const uint32_t z0 = readlane(R.size(), 0), z1 = readlane(R.size(), 16), z2 = readlane(R.size(), 32), z3 = readlane(R.size(), 48);
 	const uint32_t n0 = B.act[0] ? 1u : 0u, n1 = B.act[1] ? 1u : 0u, n2 = B.act[2] ? 1u : 0u, n3 = B.act[3] ? 1u : 0u;
 	const uint32_t s1 = n0, s2 = n0 + n1, s3 = n0 + n1 + n2; // the slot blocks 1, 2, 3 would take
 	B.full[0] = (n0 ? z0 : 0u) + (T - n0);
@@ -504,9 +507,9 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 		const Pred leads = (r >= U32(4u)) & (r < U32(8u)) & (before < P.k) & ((P.act & ((U32(1u) << P.k) - 1u)) == U32(0u));
 		const U32 plane = sel(follows, P.k + r, before);
 		const U32 byte = (P.first >> (plane << 3)) & 0xFFu;
-		const U32 where = sel(follows, pbase + R.size + after, bbase + U32(hs) + before);
+		const U32 where = sel(follows, pbase + R.size() + after, bbase + U32(hs) + before);
 		const Pred nib = r == U32(0u);
-		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type, byte), P.valid & (nib | follows | leads), own);
+		put_small(out, sel(nib, bbase * 8u + P.k * 4u, where * 8u), sel(nib, R.type(), byte), P.valid & (nib | follows | leads), own);
 	}
 	// a block without a slot: its SAME bytes (the type nibbles are all 0); constant indices keep the batch in scalar registers
 #define STENOS_SAME_ONLY(q)                                                                                             \
@@ -524,14 +527,14 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 		return;
 	}
 	WV_MARK("emit_rowlanes");
-	const U32 hdr = R.hdr;
-	const Pred israw = P.valid & (R.type == U32(PLANE_RAW));
+	const U32 hdr = R.hdr();
+	const Pred israw = P.valid & (R.type() == U32(PLANE_RAW));
 	const Pred normal = P.valid & !israw;
 	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
-	put_small(out, (pbase + R.minpos) * 8u, R.minb ^ 0x80u, normal & R.emitmin, own);
+	put_small(out, (pbase + (R.pm >> 16)) * 8u, R.minb() ^ 0x80u, normal & R.emitmin, own);
 	{
 		// mins rle mask (:765): bit r = min equals previous min
-		const Pred isnrle = normal & (R.type == U32(PLANE_NORMAL_RLE));
+		const Pred isnrle = normal & (R.type() == U32(PLANE_NORMAL_RLE));
 		if (any(isnrle)) {
 			const U32 m16 = row_ballot16(R.eq);
 			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
@@ -543,7 +546,7 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 	const Pred rawrow = israw | (normal & is15);
 	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
 	const Pred rle = normal & isr;
-	const U32 rbase = pbase + sel(israw, r * 16u, R.poff);
+	const U32 rbase = pbase + sel(israw, r * 16u, R.pm & 0xFFFFu);
 	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {

@@ -290,8 +290,6 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					keys0 = lz_distinct_keys_fast<2>(lds, M, ea.e);
 				if (T == 4 && nblk > 1 && B.nslots - B.nact0 >= 2)
 					keys1 = lz_distinct_keys_fast<2>(lds, M, eb.e);
-				// what the row lanes need to know about a pass of this shape: requested now, used behind the analysis
-				const U32 shape_e = shape_lane_entry(T, B.act[0] | (B.act[1] << 4));
 				write_slots_fast(lds, M, ea, T, B.act[0], 0);
 				if (nblk > 1)
 					write_slots_fast(lds, M, eb, T, B.act[1], B.nact0);
@@ -325,7 +323,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 							}
 						}
 						nblk = W.nblk;
-						wide_ahead = nblocks > 3 ? nblocks - 3 : 0; // (i + 3 < nblocks)
+						wide_ahead = first_lane_value(nblocks > 3 ? nblocks - 3 : 0); // (i + 3 < nblocks; said to be uniform: it is assigned under a condition the compiler takes for divergent)
 					}
 				} }
 				if (sink.raw_to) { // (measured only, probably a copy: the raw bytes go where the copy would put them)
@@ -345,7 +343,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					else {
 						for (int k = 0; k < 4; ++k)
 							R.sb[k] = R.sd[k] = U32(0u);
-						R.hdr = R.minb = R.poff = R.minpos = R.type = R.size = U32(0u);
+						R.hm = R.pm = R.ts = U32(0u);
 						R.emitmin = R.eq = pred_all(false);
 					}
 					uint32_t base[4];
@@ -367,11 +365,13 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				else { // only constant planes: nothing to measure
 					for (int k = 0; k < 4; ++k)
 						R.sb[k] = R.sd[k] = U32(0u);
-					R.hdr = R.minb = R.poff = R.minpos = R.type = R.size = U32(0u);
+					R.hm = R.pm = R.ts = U32(0u);
 					R.emitmin = R.eq = pred_all(false);
 				}
 				WV_MARK("plane_offsets");
-				const SlotPlace P = slot_rows_place(R, B, T, shape_e);
+				// what the row lanes need to know about a pass of this shape (one table load: it hits the first-level cache, the
+				// shapes of a run hardly change; asking for it in front of the analysis costs a register there)
+				const SlotPlace P = slot_rows_place(R, B, T, shape_lane_entry(T, B.act[0] | (B.act[1] << 4)));
 				if (T == 4) {
 					// Those that pass the rejection tests.  The key counts cover the first 40 values (most blocks fail there); a block
 					// they do not turn away is looked at again: first the test that turns noise and floats away (values that hardly
