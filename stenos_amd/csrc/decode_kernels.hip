@@ -20,8 +20,14 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 
+// Waves per SIMD the kernel for bytesoftype TT is compiled for.  bytesoftype 8: a wave's window and image take 7 KB of LDS,
+// so a CU holds 23 of them (five to six per SIMD) whatever is said here; saying six gives the kernel 80 vector registers.
+#ifndef STENOS_DECODE_OCCUPANCY_T8
+#define STENOS_DECODE_OCCUPANCY_T8 8
+#endif
+constexpr uint32_t decode_occupancy(uint32_t TT) { return TT == 8 ? STENOS_DECODE_OCCUPANCY_T8 : 8; }
 template <uint32_t TT>
-__global__ __launch_bounds__(64, 8) void decode_superblocks(DecodeArgs a)
+__global__ __launch_bounds__(64, decode_occupancy(TT)) void decode_superblocks(DecodeArgs a)
 {
 	const uint32_t T = TT ? TT : a.T;
 	const uint64_t s = a.sb_ids ? a.sb_ids[blockIdx.x] : blockIdx.x;

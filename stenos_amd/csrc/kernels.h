@@ -58,7 +58,7 @@ hipError_t stenos_k_launch_shuffle(const uint8_t* src, uint8_t* dst, uint32_t T,
 hipError_t stenos_k_launch_init(uint8_t* misc, uint64_t first_off, uint64_t* z1, uint64_t n1, uint64_t* z2, uint64_t n2, hipStream_t stream);
 hipError_t stenos_k_launch_encode_fused(const codec::FrameJob& j, uint64_t nsb, uint8_t* stage, uint64_t* desc, uint32_t* ticket, uint64_t* carry, hipStream_t stream);
 bool stenos_k_fused_supported(uint32_t T);
-uint32_t stenos_k_fused_groups(uint64_t nsb);
+uint32_t stenos_k_fused_groups(uint64_t nsb, uint32_t T);
 size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb);
 hipError_t stenos_k_launch_delta(const uint8_t* src, uint8_t* dst, uint64_t bytes, bool inverse, hipStream_t stream);
 hipError_t stenos_k_launch_gather_pieces(const uint8_t* src, uint64_t stride, const uint64_t* off, const uint64_t* size, uint32_t count, uint8_t* dst, hipStream_t stream);

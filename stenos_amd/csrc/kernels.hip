@@ -80,6 +80,13 @@ constexpr uint64_t CHAIN_FAILED = ~0ull;
 #define STENOS_FUSED_OCCUPANCY 8
 #endif
 constexpr uint32_t FUSED_OCCUPANCY = STENOS_FUSED_OCCUPANCY;
+// Waves per SIMD the kernel for bytesoftype TT is compiled for (and, times four SIMDs, the workgroups that stay resident per
+// CU).  bytesoftype 8: its four waves need 30 KB of LDS, so five workgroups are all a CU holds anyway -- saying so gives the
+// plane-group encoder 96 vector registers instead of 64 (double sine: 8.5 -> 8.2 ms per 8 GiB).
+#ifndef STENOS_FUSED_OCCUPANCY_T8
+#define STENOS_FUSED_OCCUPANCY_T8 5
+#endif
+constexpr uint32_t fused_occupancy(uint32_t TT) { return TT == 8 ? STENOS_FUSED_OCCUPANCY_T8 : FUSED_OCCUPANCY; }
 #ifndef STENOS_FUSED_TICKETS
 #define STENOS_FUSED_TICKETS 0
 #endif
@@ -171,7 +178,7 @@ __device__ uint64_t chain_wait(const FrameJob& j, uint64_t s)
 // store the previous superblock at its offset (pipeline.h, fused_store): by then the scanner has normally passed it.
 // A workgroup owns two staging buffers and alternates between them.
 template <uint32_t TT>
-__global__ __launch_bounds__(64 * FUSED_WAVES, FUSED_OCCUPANCY) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
+__global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_superblocks(FrameJob j, uint64_t nsb, uint8_t* __restrict__ stage, uint32_t run_cap,
 									uint64_t* __restrict__ size, uint32_t* __restrict__ ticket, uint64_t* __restrict__ carry)
 {
 	if (blockIdx.x == 0) {
@@ -399,7 +406,7 @@ static hipError_t launch_fused_t(const FrameJob& j, uint64_t nsb, uint8_t* stage
 	hipError_t e = hipFuncSetAttribute((const void*)encode_superblocks<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess)
 		return e;
-	const uint32_t grid = stenos_k_fused_groups(nsb) + 1; // + the scanner
+	const uint32_t grid = stenos_k_fused_groups(nsb, j.T) + 1; // + the scanner
 	hipLaunchKernelGGL((encode_superblocks<TT>), dim3(grid), dim3(64 * FUSED_WAVES), lds, stream, j, nsb, stage, fused_run_capacity(j.bps, j.T), desc, ticket, carry);
 	return hipGetLastError();
 }
@@ -421,15 +428,15 @@ hipError_t stenos_k_launch_encode_fused(const FrameJob& j, uint64_t nsb, uint8_t
 // the workgroup's scratch must fit the 160 KiB of a CU (bytesoftype up to about 40)
 bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FUSED_WAVES * stenos_k_encode_lds_bytes(T) + 32 + 8 * FUSED_WAVES <= 160u * 1024u; }
 // encoder workgroups of the fused kernel: as many as stay resident (they take superblocks until none is left)
-uint32_t stenos_k_fused_groups(uint64_t nsb)
+uint32_t stenos_k_fused_groups(uint64_t nsb, uint32_t T)
 {
 	if (FUSED_TICKETS)
 		return (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS);
-	const uint64_t resident = (uint64_t)stenos_k_cu_count() * (32 / FUSED_WAVES); // eight waves per SIMD
+	const uint64_t resident = (uint64_t)stenos_k_cu_count() * (fused_occupancy(T) * 4 / FUSED_WAVES); // waves per SIMD x four SIMDs
 	return (uint32_t)(nsb < resident ? nsb : resident);
 }
 // two staging buffers per workgroup
-size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb) { return (size_t)stenos_k_fused_groups(nsb) * 2 * FUSED_WAVES * fused_run_capacity(bps, T) + 64; }
+size_t stenos_k_fused_stage_bytes(uint32_t T, uint32_t bps, uint64_t nsb) { return (size_t)stenos_k_fused_groups(nsb, T) * 2 * FUSED_WAVES * fused_run_capacity(bps, T) + 64; }
 
 // blocks [b_begin, b_end) of the job (the tail block has index nfull)
 hipError_t stenos_k_launch_encode(const FrameJob& j, uint64_t b_begin, uint64_t b_end, hipStream_t stream)
