@@ -231,8 +231,11 @@ def measure_other(name, torch, dist, dev, with_cpu):
          "decode_indexed_gbps": round(nb * steps / r["dec_indexed_s"] / 1e9, 3), "decode_input": "the frame alone (header chain walked on the device inside the timed region)"}
     if level == 1 and T > 1:
         algo = nb + r["csize"]
-        roof = roofline("encode_superblocks", algo, r["kenc_ms"])
-        roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"]).items() if k in ("achieved", "frac", "kernel_ms")}
+        key = {"walk": "int16", "sine": "double"}.get(kind) if gib == 8.0 else None
+        t_enc, src_enc = profiled_traffic(key)
+        t_dec, _ = profiled_traffic(key, "decode_superblocks")
+        roof = roofline("encode_superblocks", algo, r["kenc_ms"], t_enc, src_enc)
+        roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"], t_dec).items() if k in ("achieved", "frac", "kernel_ms", "traffic")}
         e["roofline"] = roof
     else:
         e["roofline"] = None
@@ -252,6 +255,26 @@ def measure_other(name, torch, dist, dev, with_cpu):
     del src
     torch.cuda.empty_cache()
     return e
+
+
+# Counters cannot be collected inside a bench run: the HBM traffic of a configuration is the figure of the committed profile
+# of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_config.sh + tools/pmc_summary.py,
+# with the FETCH x 2 correction of the guide), quoted with its origin.
+TRAFFIC_PROFILES = {"int32": "pmc_traffic.json", "int32_rand": "r04_pmc_int32_rand.json", "int16": "r04_pmc_int16.json", "double": "r04_pmc_double.json"}
+
+
+def profiled_traffic(key, kernel="encode_superblocks"):
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILES.get(key, ""))
+    if key not in TRAFFIC_PROFILES or not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        t = j.get(f"{kernel}_hbm_bytes_per_launch")
+        src = f"profiles/{TRAFFIC_PROFILES[key]} ({j.get('profile', '?')}, build {j.get('build', '?')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload, separate passes"
+        return t, (src if t else None)
+    except Exception:
+        return None, None
 
 
 def roofline(kernel, algo_bytes, kernel_ms, traffic=None, traffic_source=None):
@@ -399,19 +422,11 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (encode_superblocks, the fused encoder): algorithmic bytes = N read + C written per launch
         algo = nbytes + r["csize"]
-        traffic = source = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.config == "int32" and not args.kind and args.gib == 8.0 and os.path.exists(pmc):
-            # counters cannot be collected inside this run: the figure is the one of the committed profile, with its origin
-            try:
-                with open(pmc) as f:
-                    j = json.load(f)
-                traffic = j.get("encode_superblocks_hbm_bytes_per_launch")
-                source = f"profiles/pmc_traffic.json ({j.get('profile', '?')}, build {j.get('build', '?')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload, separate passes"
-            except Exception:
-                traffic = source = None
+        key = {"int32": "int32", "int16": "int16", "double": "double"}[args.config] if not args.kind and args.gib == 8.0 else None
+        traffic, source = profiled_traffic(key)
+        t_dec, _ = profiled_traffic(key, "decode_superblocks")
         roof = roofline("encode_superblocks", algo, r["kenc_ms"], traffic, source)
-        roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"]).items() if k in ("achieved", "frac", "kernel_ms")}
+        roof["decode_superblocks"] = {k: v for k, v in roofline("decode_superblocks", algo, r["kdec_ms"], t_dec).items() if k in ("achieved", "frac", "kernel_ms", "traffic")}
         if world == 1:
             try:
                 roof["device_copy"] = device_copy_rate(torch, dev)
@@ -448,8 +463,10 @@ def main():
         r2 = run_workload(st, torch, src2, T, k, 1, dist, world)
         assert r2["ok"]
         algo2 = nbytes + r2["csize"]
-        roof2 = roofline("encode_superblocks", algo2, r2["kenc_ms"])
-        roof2["decode_superblocks"] = {kk: v for kk, v in roofline("decode_superblocks", algo2, r2["kdec_ms"]).items() if kk in ("achieved", "frac", "kernel_ms")}
+        t2, s2 = profiled_traffic("int32_rand" if args.gib == 8.0 else None)
+        t2d, _ = profiled_traffic("int32_rand" if args.gib == 8.0 else None, "decode_superblocks")
+        roof2 = roofline("encode_superblocks", algo2, r2["kenc_ms"], t2, s2)
+        roof2["decode_superblocks"] = {kk: v for kk, v in roofline("decode_superblocks", algo2, r2["kdec_ms"], t2d).items() if kk in ("achieved", "frac", "kernel_ms", "traffic")}
         out["full_entropy"] = {"workload": "the literal configs[1]: uniform 32-bit values (splitmix64 seed 42), every superblock stored as a copy",
                                "value": round(nbytes * k / r2["wall"] / 1e9, 3), "compression_ratio": round(nbytes / r2["csize"], 5),
                                "encode_gbps": round(nbytes * k / r2["enc_s"] / 1e9, 3), "decode_gbps": round(nbytes * k / r2["dec_s"] / 1e9, 3),

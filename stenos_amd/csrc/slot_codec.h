@@ -276,20 +276,26 @@ struct SlotPlace {
 	U32 pbase, e, first;
 	Pred valid, second;
 };
-// e: shape_lane_entry(T, B.act[0] | B.act[1] << 4), requested when the batch was formed
-WV_FN SlotPlace slot_rows_place(const SlotRows& R, SlotBatch& B, uint32_t T, const U32& e)
+// The sizes of the batch's blocks (B.full) and, for the emission, where every slot's plane goes.  incl: inclusive sums of the
+// plane sizes over the slots (the value of a slot is the same in its 16 lanes).
+WV_FN U32 slot_rows_sizes(const SlotRows& R, SlotBatch& B, uint32_t T, uint32_t* p0_out)
 {
-	SlotPlace P;
-	P.e = e;
-	P.valid = (e & 8u) != U32(0u);
-	P.second = (e & 4u) != U32(0u);
-	// inclusive sums of the plane sizes over the slots (the value of a slot is the same in its 16 lanes)
 	U32 incl = R.size() + scan_source(R.size(), 4, 0u);
 	incl = incl + scan_source(incl, 5, 0u);
 	const uint32_t p0 = B.nact0 ? readlane(incl, 16u * B.nact0 - 1u) : 0u;
 	const uint32_t pt = B.nslots ? readlane(incl, 16u * B.nslots - 1u) : 0u;
 	B.full[0] = p0 + (T - B.nact0);
 	B.full[1] = B.nblk > 1 ? pt - p0 + (T - (B.nslots - B.nact0)) : 0u;
+	*p0_out = p0;
+	return incl;
+}
+// e: shape_lane_entry(T, B.act[0] | B.act[1] << 4); incl, p0: from slot_rows_sizes
+WV_FN SlotPlace slot_rows_place(const SlotRows& R, const SlotBatch& B, uint32_t T, const U32& e, const U32& incl, uint32_t p0)
+{
+	SlotPlace P;
+	P.e = e;
+	P.valid = (e & 8u) != U32(0u);
+	P.second = (e & 4u) != U32(0u);
 	P.first = sel(P.second, U32(B.first[1]), U32(B.first[0]));
 	// planes before mine in my block: SAME ones take a byte each (k - j of them), the others are the slots before mine
 	P.pbase = U32(header_bytes(T)) + ((e >> 4) & 3u) + (incl - R.size() - sel(P.second, U32(p0), U32(0u)));

@@ -369,9 +369,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					R.emitmin = R.eq = pred_all(false);
 				}
 				WV_MARK("plane_offsets");
-				// what the row lanes need to know about a pass of this shape (one table load: it hits the first-level cache, the
-				// shapes of a run hardly change; asking for it in front of the analysis costs a register there)
-				const SlotPlace P = slot_rows_place(R, B, T, shape_lane_entry(T, B.act[0] | (B.act[1] << 4)));
+				uint32_t p0;
+				const U32 incl = slot_rows_sizes(R, B, T, &p0);
 				if (T == 4) {
 					// Those that pass the rejection tests.  The key counts cover the first 40 values (most blocks fail there); a block
 					// they do not turn away is looked at again: first the test that turns noise and floats away (values that hardly
@@ -390,7 +389,10 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 				if (!lzq) {
 					const uint32_t base = sink.base(), size0 = hs + B.full[0], size1 = nblk > 1 ? hs + B.full[1] : 0u;
-					if (sink.writes) {
+					if (sink.writes) { // (a pass that is only measured needs the sizes, not the places)
+						// what the row lanes need to know about a pass of this shape: one table load -- it hits the first-level cache, the
+						// shapes of a run hardly change, and asking for it in front of the analysis would cost a register there
+						const SlotPlace P = slot_rows_place(R, B, T, shape_lane_entry(T, B.act[0] | (B.act[1] << 4)), incl, p0);
 						WV_MARK("image_reset");
 						image_reset_fixed(lds, M, T);
 						slot_rows_emit(lds, M, T, R, P, B, base, base + size0);

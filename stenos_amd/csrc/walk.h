@@ -34,10 +34,16 @@
 
 namespace walk {
 
-constexpr uint32_t MAX_SEGMENTS = 2048;
+#ifndef STENOS_WALK_MAX_SEGMENTS
+#define STENOS_WALK_MAX_SEGMENTS 2048
+#endif
+#ifndef STENOS_WALK_SEG_WINDOWS
+#define STENOS_WALK_SEG_WINDOWS 4
+#endif
+constexpr uint32_t MAX_SEGMENTS = STENOS_WALK_MAX_SEGMENTS;
 constexpr uint32_t LANES = 64;
 constexpr uint32_t MIN_SEGMENTS = 4;       // below, the serial walk
-constexpr uint32_t SEG_WINDOWS = 4;        // a segment is at least this many windows long
+constexpr uint32_t SEG_WINDOWS = STENOS_WALK_SEG_WINDOWS; // a segment is at least this many windows long
 constexpr uint32_t PROOF_HOPS = 2;         // plausible headers a speculated chain must meet behind its segment
 enum : uint32_t { SEG_UNRESOLVED = 0, SEG_OK = 1 };
 enum : uint32_t { WALK_FAILED = 1 };

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/pmc (tools/pmc_run.sh) per kernel and write profiles/pmc_traffic.json.
+usage: pmc_summary.py <tag> [input bytes] [directory under gpurun_out (default pmc)] [config name]
+With a config name (tools/pmc_config.sh: int16, double, float32 ...) the summary goes to profiles/<tag>_pmc_<config>.json and
+profiles/pmc_traffic.json is left alone (it belongs to the headline).
 HBM bytes per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024: on gfx950 FETCH_SIZE reports half of a
 wide coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte stores."""
 import collections
@@ -12,11 +15,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 input_bytes = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0 * (1 << 30)  # bytes of the profiled workload
+subdir = sys.argv[3] if len(sys.argv) > 3 else "pmc"
+config = sys.argv[4] if len(sys.argv) > 4 else None
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 full_names = collections.defaultdict(lambda: collections.defaultdict(int))  # base name -> counter -> {full kernel name: rows}
 # gpurun merges new outputs into the local directory: keep only the newest collection of every pass
 newest = {}
-for p in glob.glob(os.path.join(ROOT, "gpurun_out/pmc/p*/*/*_counter_collection.csv")):
+for p in glob.glob(os.path.join(ROOT, "gpurun_out", subdir, "p*/*/*_counter_collection.csv")):
     d = os.path.dirname(p)
     if d not in newest or os.path.getmtime(p) > os.path.getmtime(newest[d]):
         newest[d] = p
@@ -58,12 +63,17 @@ try:
         build += "+local changes"
 except Exception:
     build = "unknown"
-res["profile"] = f"{tag}_pmc_counters.json"
+name_out = f"{tag}_pmc_{config}.json" if config else f"{tag}_pmc_counters.json"
+res["profile"] = name_out
 res["build"] = build  # the sources the counters were collected from: bench.py quotes it next to roofline.traffic
-with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json"), "w") as f:
+if config:
+    res["config"] = config
+    res["source"] = f"rocprofv3 --pmc (tools/pmc_config.sh {config}), bench.py --config ... --steps 1 --warmup 0, separate passes"
+with open(os.path.join(ROOT, "profiles", name_out), "w") as f:
     json.dump(res, f, indent=1)
-with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
-    json.dump({k: v for k, v in res.items() if k != "kernels"}, f, indent=1)
+if not config:
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump({k: v for k, v in res.items() if k != "kernels"}, f, indent=1)
 for name, cs in out.items():
     w = cs.get("SQ_WAVES", 0)
     line = f"{name:20s}"
