@@ -351,42 +351,19 @@ WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const P
 	lds_put_bytes8(out, sel(anyw, rbase + ebits, dump), s1lo | pk[2], s1hi);
 }
 
-// Write the blocks of the batch into the zeroed image, block i at byte base[i]: type nibbles, SAME bytes, row headers,
-// minima and payloads (block_compress.h:739-806, 1246-1257).
-WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& R, const SlotPlace& P, const SlotBatch& B, uint32_t base0, uint32_t base1)
+// The rows of the slots into the zeroed image, once every slot knows where its plane starts (pbase, from the image's start):
+// header nibbles, minima, the mask of repeated minima, payloads (block_compress.h:739-806).  Shared by the three batch forms.
+WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, const Pred& valid, const U32& pbase)
 {
 	const U32 lane = lane_id();
 	const U32 r = lane & 15u;
 	const U32 H(0x80808080u);
 	Lds out = lds + L.out;
-	const uint32_t hs = header_bytes(T);
 	const U32 own = U32(slot2_area(L) - L.out) + lane * 16u; // where lanes with nothing to write OR what they have (outside the image)
-	WV_MARK("emit_nibbles");
-	const U32 bbase = sel(P.second, U32(base1), U32(base0));
-	const U32 pbase = bbase + P.pbase;
-	{
-		// One small write per lane of a slot, as the shape table says: lane 0 the plane's type nibble (:1246-1257); lanes 1..3
-		// the bytes of the SAME planes that follow the plane directly; lanes 4..7 of a block's first slot the SAME planes in
-		// front of it (:747-750).  Bit position: the table's constant from the block's start or from the end of the plane.
-		const U32 role = (P.e >> 6) & 3u;
-		const U32 byte = (P.first >> ((P.e >> 8) & 31u)) & 0xFFu;
-		const U32 from = sel(role == U32(2u), pbase + R.size(), bbase);
-		const Pred nib = role == U32(1u);
-		put_small(out, from * 8u + ((P.e >> 13) & 63u), sel(nib, R.type(), byte), role != U32(0u), own);
-	}
-	for (uint32_t i = 0; i < B.nblk; ++i) // a block without a slot: its SAME bytes (the type nibbles are all 0)
-		if (B.act[i] == 0) {
-			const U32 byte = (U32(B.first[i]) >> (lane << 3)) & 0xFFu;
-			put_small(out, (U32((i ? base1 : base0) + hs) + lane) * 8u, byte, lane < U32(T), own);
-		}
-	if (B.nslots == 0) {
-		wave_sync();
-		return;
-	}
 	WV_MARK("emit_rowlanes");
 	const U32 hdr = R.hdr();
-	const Pred israw = P.valid & (R.type() == U32(PLANE_RAW));
-	const Pred normal = P.valid & !israw;
+	const Pred israw = valid & (R.type() == U32(PLANE_RAW));
+	const Pred normal = valid & !israw;
 	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
 	put_small(out, (pbase + (R.pm >> 16)) * 8u, R.minb() ^ 0x80u, normal & R.emitmin, own);
 	{
@@ -438,6 +415,39 @@ WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& 
 	}
 	WV_MARK("emit_end");
 	wave_sync();
+}
+
+// Write the blocks of the batch into the zeroed image, block i at byte base[i]: type nibbles, SAME bytes, row headers,
+// minima and payloads (block_compress.h:739-806, 1246-1257).
+WV_FN void slot_rows_emit(Lds lds, const Layout& L, uint32_t T, const SlotRows& R, const SlotPlace& P, const SlotBatch& B, uint32_t base0, uint32_t base1)
+{
+	const U32 lane = lane_id();
+	Lds out = lds + L.out;
+	const uint32_t hs = header_bytes(T);
+	const U32 own = U32(slot2_area(L) - L.out) + lane * 16u; // where lanes with nothing to write OR what they have (outside the image)
+	WV_MARK("emit_nibbles");
+	const U32 bbase = sel(P.second, U32(base1), U32(base0));
+	const U32 pbase = bbase + P.pbase;
+	{
+		// One small write per lane of a slot, as the shape table says: lane 0 the plane's type nibble (:1246-1257); lanes 1..3
+		// the bytes of the SAME planes that follow the plane directly; lanes 4..7 of a block's first slot the SAME planes in
+		// front of it (:747-750).  Bit position: the table's constant from the block's start or from the end of the plane.
+		const U32 role = (P.e >> 6) & 3u;
+		const U32 byte = (P.first >> ((P.e >> 8) & 31u)) & 0xFFu;
+		const U32 from = sel(role == U32(2u), pbase + R.size(), bbase);
+		const Pred nib = role == U32(1u);
+		put_small(out, from * 8u + ((P.e >> 13) & 63u), sel(nib, R.type(), byte), role != U32(0u), own);
+	}
+	for (uint32_t i = 0; i < B.nblk; ++i) // a block without a slot: its SAME bytes (the type nibbles are all 0)
+		if (B.act[i] == 0) {
+			const U32 byte = (U32(B.first[i]) >> (lane << 3)) & 0xFFu;
+			put_small(out, (U32((i ? base1 : base0) + hs) + lane) * 8u, byte, lane < U32(T), own);
+		}
+	if (B.nslots == 0) {
+		wave_sync();
+		return;
+	}
+	slot_rows_emit_rows(lds, L, R, P.valid, pbase);
 }
 
 // A wide batch: three or four consecutive blocks with at most one non-constant plane each (small integers in wide
@@ -532,61 +542,7 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 		wave_sync();
 		return;
 	}
-	WV_MARK("emit_rowlanes");
-	const U32 hdr = R.hdr();
-	const Pred israw = P.valid & (R.type() == U32(PLANE_RAW));
-	const Pred normal = P.valid & !israw;
-	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
-	put_small(out, (pbase + (R.pm >> 16)) * 8u, R.minb() ^ 0x80u, normal & R.emitmin, own);
-	{
-		// mins rle mask (:765): bit r = min equals previous min
-		const Pred isnrle = normal & (R.type() == U32(PLANE_NORMAL_RLE));
-		if (any(isnrle)) {
-			const U32 m16 = row_ballot16(R.eq);
-			put_bits(out, (pbase + 8u) * 8u, m16, isnrle & (r == U32(0u)), own);
-		}
-	}
-	WV_MARK("emit_plane");
-	const Pred is15 = hdr == U32(15u), isr = (hdr & 14u) == U32(6u);
-	const U32 bits = hdr & 7u;
-	const Pred rawrow = israw | (normal & is15);
-	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
-	const Pred rle = normal & isr;
-	const U32 rbase = pbase + sel(israw, r * 16u, R.pm & 0xFFFFu);
-	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
-	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
-	if (any(rle)) {
-		const Pred is7 = hdr == U32(7u);
-		// table of the 16 v_perm_b32 selectors that move the bytes whose flag is 0 to the low end (lane f writes entry f;
-		// the row table of the plane-group path is not used here)
-		const uint32_t lut = L.rowinfo; // (free on this path; the slot area takes what idle lanes OR away, see put_small)
-		{
-			U32 pat(0x0c0c0c0cu), at(0u);
-			for (uint32_t k = 0; k < 4; ++k) {
-				const Pred keep = ((lane >> k) & 1u) == U32(0u);
-				pat = sel(keep, (pat & ~(U32(0xFFu) << at)) | (U32(k) << at), pat);
-				at = at + sel(keep, U32(8u), U32(0u));
-			}
-			lds_st32(lds, U32(lut) + lane * 4u, pat, lane < U32(16u));
-			wave_sync();
-		}
-		U32 f16(0u), lp = rbase + 2u;
-		for (int k = 0; k < 4; ++k) {
-			// byte == previous byte (:268-275) / delta == previous delta (:248-255)
-			const U32 bp = k ? prev_bytes(R.sb[k], R.sb[k - 1]) : prev_bytes(R.sb[0], row_shr(R.sb[3], 1, 0x80808080u));
-			const U32 dp = k ? prev_bytes(R.sd[k], R.sd[k - 1]) : ((R.sd[0] << 8) | 0x80u);
-			const U32 z = bytes_zero_mask(sel(is7, R.sb[k] ^ bp, R.sd[k] ^ dp));
-			const U32 f = zero_mask_to_bits(z);
-			f16 = f16 | (f << U32(4u * (uint32_t)k));
-			const U32 nlit = U32(4u) - popc(f);
-			const U32 lits = perm_bytes_v(U32(0u), sel(is7, R.sb[k], R.sd[k]) ^ H, lds_ld32(lds, U32(lut) + f * 4u));
-			put_bits(out, lp * 8u, lits, rle & (nlit != U32(0u)), own);
-			lp = lp + nlit;
-		}
-		put_bits(out, rbase * 8u, f16, rle, own);
-	}
-	WV_MARK("emit_end");
-	wave_sync();
+	slot_rows_emit_rows(lds, L, R, P.valid, pbase);
 }
 
 } // namespace codec
