@@ -545,4 +545,140 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 	slot_rows_emit_rows(lds, L, R, P.valid, pbase);
 }
 
+// ---- bytesoftype 8 -----------------------------------------------------------------------------------------------------
+// One block per batch: its non-constant planes take the four slots in plane order, the first four in one pass, the rest
+// (doubles and 64-bit integers seldom have fewer than five) in a second one.  Both passes are analysed before anything is
+// written -- the mini-LZ decision needs the block's whole size -- and then emitted one behind the other.  A lane holds four
+// consecutive elements as (low, high) dword pairs; the low halves carry planes 0..3, the high halves planes 4..7, so the
+// 4 x 4 byte transposes of bytesoftype 4 serve each half.
+struct RawBlock8 {
+	U128 a, b; // elements 4 lane + 0, 1 in a (low, high, low, high), 4 lane + 2, 3 in b
+};
+WV_FN RawBlock8 load_raw_block8(const uint8_t* g)
+{
+	RawBlock8 r;
+	r.a = gld128_unaligned(g, lane_id() * 32u, pred_all(true));
+	r.b = gld128_unaligned(g, lane_id() * 32u + 16u, pred_all(true));
+	return r;
+}
+WV_FN RawBlock half_of(const RawBlock8& b, bool high)
+{
+	RawBlock h;
+	h.e.x = high ? b.a.y : b.a.x;
+	h.e.y = high ? b.a.w : b.a.z;
+	h.e.z = high ? b.b.y : b.b.x;
+	h.e.w = high ? b.b.w : b.b.z;
+	return h;
+}
+struct SameScan8 {
+	uint32_t act, nact;          // bit k: plane k is not constant
+	uint32_t first_lo, first_hi; // the first element (the bytes of the SAME planes)
+};
+WV_FN SameScan8 scan_same8(const RawBlock8& b)
+{
+	SameScan8 s;
+	s.first_lo = readlane(b.a.x, 0);
+	s.first_hi = readlane(b.a.y, 0);
+	const U32 f0(s.first_lo), f1(s.first_hi);
+	const U32 xl = ((b.a.x ^ f0) | (b.a.z ^ f0)) | ((b.b.x ^ f0) | (b.b.z ^ f0));
+	const U32 xh = ((b.a.y ^ f1) | (b.a.w ^ f1)) | ((b.b.y ^ f1) | (b.b.w ^ f1));
+	s.act = mask_bit<1>(ballot((xl & 0xFFu) != U32(0u))) | mask_bit<2>(ballot((xl & 0xFF00u) != U32(0u))) | mask_bit<4>(ballot((xl & 0xFF0000u) != U32(0u))) |
+		mask_bit<8>(ballot((xl & 0xFF000000u) != U32(0u))) | mask_bit<16>(ballot((xh & 0xFFu) != U32(0u))) | mask_bit<32>(ballot((xh & 0xFF00u) != U32(0u))) |
+		mask_bit<64>(ballot((xh & 0xFF0000u) != U32(0u))) | mask_bit<128>(ballot((xh & 0xFF000000u) != U32(0u)));
+	s.nact = (uint32_t)__builtin_popcount(s.act);
+	return s;
+}
+// the planes of mask m (at most four) into slots 0, 1, ... in plane order
+WV_FN void write_slots8(Lds lds, const Layout& L, const RawBlock8& b, uint32_t m)
+{
+	if (m & 15u)
+		write_slots_fast(lds, L, half_of(b, false), 4, m & 15u, 0);
+	if (m >> 4)
+		write_slots_fast(lds, L, half_of(b, true), 4, m >> 4, (uint32_t)__builtin_popcount(m & 15u));
+}
+// Distinct hash keys among the first 80 values (all the reference's early-stop test sees, lz_precheck_values(8)): lanes
+// 0..19 hold them, value k of a lane in round k.  As lz_distinct_keys_fast, with a key of its own (below).
+WV_FN uint32_t lz_distinct_keys_fast8(Lds lds, const Layout& L, const RawBlock8& b)
+{
+	uint32_t distinct = 0;
+	lanes_below(lz_precheck_values(8) / 4, [&](const Pred& in) {
+		const U32 lane = lane_id();
+		const U32 lo[4] = { b.a.x, b.a.z, b.b.x, b.b.z }, hi[4] = { b.a.y, b.a.w, b.b.y, b.b.w };
+		U32 addr[4];
+		for (int k = 0; k < 4; ++k) {
+			// (any function of the value serves: a value can only match behind an equal one, which has the same key under every
+			// hash, so the values that are the first with their key cannot match whatever table the reference keeps -- the bound
+			// stays a lower bound of what the reference produces; the xor of the value's bytes costs five cheap instructions, the
+			// reference's 64-bit multiplication three slow ones)
+			U32 t = lo[k] ^ hi[k];
+			t = t ^ (t >> 16);
+			t = (t ^ (t >> 8)) & 0xFFu;
+			addr[k] = U32(L.tab) + t * 4u;
+			lds_st32(lds, addr[k], lane + U32(64u * (uint32_t)k), in);
+		}
+		wave_sync();
+		for (int k = 0; k < 4; ++k)
+			distinct += (uint32_t)__builtin_popcountll(ballot(in & (lds_ld32(lds, addr[k]) == lane + U32(64u * (uint32_t)k))));
+	});
+	wave_sync();
+	return first_lane_value(distinct);
+}
+// Second rejection test of the mini-LZ for a block of bytesoftype 8 in registers (as lz_repeats_reject): a value can only
+// match when an equal value precedes it; one bit per 13-bit hash of the 8-byte value bounds the number of such values from
+// above, and if even with all of them matching the stream exceeds max_size the reference fails after doing all the work
+// (lz_compress.h:221-223).  True: the attempt is pointless.  (Incompressible blocks always pass the first test -- their
+// max_size is large -- and end here.)
+WV_FN bool lz_repeats_reject8(Lds lds, const Layout& L, const RawBlock8& b, uint32_t max_size)
+{
+	const U32 lane = lane_id();
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	lds_st128(lds, U32(L.tab) + lane * 16u, z, pred_all(true));
+	wave_sync();
+	const U32 lo[4] = { b.a.x, b.a.z, b.b.x, b.b.z }, hi[4] = { b.a.y, b.a.w, b.b.y, b.b.w };
+	uint32_t maybe = 0;
+	for (int k = 0; k < 4; ++k) {
+		const U32 h = ((lo[k] ^ (hi[k] * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 19;
+		const U32 bit = U32(1u) << (h & 31u);
+		const U32 old = lds_or_rtn32(lds, U32(L.tab) + (h >> 5) * 4u, bit);
+		maybe += (uint32_t)__builtin_popcountll(ballot((old & bit) != U32(0u)));
+	}
+	wave_sync();
+	return 256 / 8 + 256 * 8 - maybe * 7 > max_size;
+}
+// What lane 16*s + r has to know about pass q of a block whose planes `act` are not constant (fields: tools/gen_shape_tables.py)
+WV_FN U32 shape_lane_entry8(uint32_t act, uint32_t q)
+{
+	return gld32((const uint8_t*)SHAPE_LANES_T8 + (act * 2u + q) * 256u, lane_id() * 4u, pred_all(true));
+}
+// inclusive sums of the plane sizes over the slots of a pass; *total: the sum over its n slots
+WV_FN U32 slot_pass_sizes(const SlotRows& R, uint32_t n, uint32_t* total)
+{
+	U32 incl = R.size() + scan_source(R.size(), 4, 0u);
+	incl = incl + scan_source(incl, 5, 0u);
+	*total = n ? readlane(incl, 16u * n - 1u) : 0u;
+	return incl;
+}
+// One pass of a block of bytesoftype 8 into the zeroed image: e = shape_lane_entry8, bbase = the block's start in the image,
+// before = bytes of the non-constant planes of the pass in front, incl = slot_pass_sizes.
+WV_FN void slot_rows_emit8(Lds lds, const Layout& L, const SlotRows& R, const U32& e, const SameScan8& sc, uint32_t bbase, uint32_t before, const U32& incl)
+{
+	const U32 lane = lane_id();
+	Lds out = lds + L.out;
+	const U32 own = U32(slot2_area(L) - L.out) + lane * 16u;
+	const Pred valid = (e & 8u) != U32(0u);
+	// planes before mine: SAME ones take a byte each (k - j of them), the others are the slots before mine, in this pass and the one in front
+	const U32 pbase = U32(bbase + header_bytes(8) + before) + ((e >> 4) & 7u) + (incl - R.size());
+	{
+		// lane 0 of a slot: the plane's type nibble; lanes 1..7: bytes of the SAME planes that follow the plane directly;
+		// lanes 8..15 of the block's first slot: the SAME planes in front of it (block_compress.h:747-750, 1246-1257)
+		const U32 role = (e >> 7) & 3u;
+		const U32 f = sel((e & 0x200u) != U32(0u), U32(sc.first_hi), U32(sc.first_lo));
+		const U32 byte = (f >> ((e >> 10) & 31u)) & 0xFFu;
+		const U32 from = sel(role == U32(2u), pbase + R.size(), U32(bbase));
+		put_small(out, from * 8u + ((e >> 15) & 127u), sel(role == U32(1u), R.type(), byte), role != U32(0u), own);
+	}
+	slot_rows_emit_rows(lds, L, R, valid, pbase);
+}
+
 } // namespace codec

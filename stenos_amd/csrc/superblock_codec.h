@@ -182,6 +182,11 @@ struct StreamSink { // a contiguous stream in HBM (RunStream)
 	// nullptr: nowhere.  raw_ok turns false when a block went another way (the general encoder: not stored).
 	uint8_t* raw_to = nullptr;
 	bool raw_ok = true;
+	WV_MFN void raw8(const RawBlock8& b, uint32_t block)
+	{
+		gst128_through(raw_to + (uint64_t)block * 2048u, lane_id() * 32u, b.a);
+		gst128_through(raw_to + (uint64_t)block * 2048u, lane_id() * 32u + 16u, b.b);
+	}
 	WV_MFN void raw(const RawBlock& b, uint32_t T, uint32_t block)
 	{
 		if (T == 2)
@@ -420,6 +425,73 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			pass(std::true_type());
 		if (i < nblocks)
 			pass(std::false_type());
+		return;
+	}
+	if (slots && T == 8) {
+		// bytesoftype 8 (slot_codec.h): one block per batch, its non-constant planes in one or two passes of four slots.
+		const uint32_t bs = 2048, hs = header_bytes(8);
+		// (requesting the next block as soon as the current one has left its registers for the slots was measured: +1 % on double
+		// sine -- the eight registers it holds across the passes cost more than the wait it removes)
+		for (uint32_t i = 0; i < nblocks; ++i) {
+			const uint8_t* a = src + (uint64_t)i * bs;
+			WV_MARK("load_block");
+			const RawBlock8 eb = load_raw_block8(a);
+			const Layout M = sink.at(L);
+			WV_MARK("block_begin");
+			const SameScan8 sc = scan_same8(eb);
+			// distinct hash keys among the first 80 values: the mini-LZ's first rejection test (with fewer than three planes that are
+			// not constant the block is too small for an attempt, block_compress.h:1210)
+			const uint32_t keys = sc.nact >= 3 ? lz_distinct_keys_fast8(lds, M, eb) : 0u;
+			if (sink.raw_to) // (measured only, probably a copy: the raw bytes go where the copy would put them)
+				sink.raw8(eb, i);
+			uint32_t mask0 = sc.act, mask1 = 0; // planes of the first pass: the four lowest set bits
+			if (sc.nact > 4) {
+				uint32_t m = sc.act;
+				for (int q = 0; q < 4; ++q)
+					m &= m - 1u;
+				mask1 = m;
+				mask0 = sc.act & ~m;
+			}
+			const uint32_t n0 = sc.nact > 4 ? 4u : sc.nact, n1 = sc.nact - n0;
+			SlotRows R0, R1;
+			U32 incl0(0u), incl1(0u);
+			uint32_t pt0 = 0, pt1 = 0;
+			if (n0) {
+				write_slots8(lds, M, eb, mask0);
+				wave_sync();
+				slot_rows_analyse(lds, M, R0);
+				incl0 = slot_pass_sizes(R0, n0, &pt0);
+			}
+			if (n1) {
+				write_slots8(lds, M, eb, mask1);
+				wave_sync();
+				slot_rows_analyse(lds, M, R1);
+				incl1 = slot_pass_sizes(R1, n1, &pt1);
+			}
+			const uint32_t full = pt0 + pt1 + (8 - sc.nact);
+			if (full * 3 > bs && lz_precheck_passes(8, keys, full) && !lz_repeats_reject8(lds, M, eb, full)) { // a mini-LZ attempt: the general block encoder
+				load_block(lds, L.in, a, bs);
+				wave_sync();
+				const BlockInfo r = encode_full_block(lds, M, 8, true, sink.base());
+				sink.append(lds, M, r.size);
+				continue;
+			}
+			if (sink.writes) {
+				const uint32_t base = sink.base();
+				image_reset(lds, M, base, hs + full);
+				if (n0)
+					slot_rows_emit8(lds, M, R0, shape_lane_entry8(sc.act, 0), sc, base, 0, incl0);
+				if (n1)
+					slot_rows_emit8(lds, M, R1, shape_lane_entry8(sc.act, 1), sc, base, pt0, incl1);
+				if (sc.act == 0) { // only constant planes: their bytes (the type nibbles are all 0)
+					const U32 lane = lane_id();
+					const U32 byte = (sel(lane >= U32(4u), U32(sc.first_hi), U32(sc.first_lo)) >> ((lane & 3u) << 3)) & 0xFFu;
+					put_small(lds + M.out, (U32(base + hs) + lane) * 8u, byte, lane < U32(8u), U32(slot2_area(M) - M.out) + lane * 16u);
+					wave_sync();
+				}
+			}
+			sink.append(lds, M, hs + full);
+		}
 		return;
 	}
 	for (uint32_t i = 0; i < nblocks; ++i) {

@@ -288,6 +288,23 @@ void emul_copy_g2g_wide(uint8_t* dst, const uint8_t* src, size_t n) { copy_g2g_w
 size_t emul_lds_bytes_encode(size_t T) { return make_layout((uint32_t)T, true).total; }
 size_t emul_lds_bytes_decode(size_t T) { return make_dec_layout((uint32_t)T).total; }
 
+// a run of full blocks through encode_run (what a wave of the fused kernel does: the slot encoders for bytesoftype 2, 4, 8)
+size_t emul_run_compress(const uint8_t* src, size_t T, size_t nblocks, uint8_t* dst)
+{
+	Layout L = make_layout((uint32_t)T, true);
+	uint8_t* lds = alloc_lds(L.total);
+	uint8_t* stage = nullptr;
+	const size_t cap = nblocks * max_block_bytes((uint32_t)T) + 256;
+	if (posix_memalign((void**)&stage, 64, cap))
+		return (size_t)-3;
+	memset(stage, 0xCD, cap);
+	const uint32_t n = encode_run(lds, L, (uint32_t)T, src, (uint32_t)nblocks, stage, g_slots != 0);
+	memcpy(dst, stage, n);
+	free(stage);
+	free(lds);
+	return n;
+}
+
 // a run that is only measured while its raw bytes are put where a copy would stand (kernels.hip, speculative copy)
 size_t emul_measure_run(const uint8_t* src, size_t T, size_t nblocks, uint8_t* raw_out)
 {
