@@ -27,20 +27,20 @@ def test_the_references_own_round_trip_test_runs_against_this_library():
     """The reference's tests/tests_comp_decomp.cpp (bytesoftype 1..15 x same / sorted / random x levels 0..5 x threads 1..8 x
     shrinking dst_size, tests_comp_decomp.cpp:93-211), compiled with the reference's own header and linked with this
     library.  The whole matrix takes hours; it aborts at the first failure (STENOS_ABORT), so a bounded run that is still
-    going -- or has finished -- without an abort is a pass.  Four minutes here (about 40 000 round trips); a 960 s run
+    going -- or has finished -- without an abort is a pass.  Two and a half minutes here (about 25 000 round trips, all of the "same" distribution: the cells below reach the others); a 960 s run
     (171 640 round trips, bytesoftype 1..11, every level) is kept in profiles/r03_ref_tests_long.json."""
     import tempfile
 
     with tempfile.TemporaryFile() as log:  # (a pipe would fill up: the test prints a line per round trip)
         try:
-            rc = subprocess.run([_binary("ref_tests_comp_decomp")], stdout=log, stderr=subprocess.STDOUT, timeout=240).returncode
+            rc = subprocess.run([_binary("ref_tests_comp_decomp")], stdout=log, stderr=subprocess.STDOUT, timeout=150).returncode
         except subprocess.TimeoutExpired:
             rc = None
         log.seek(0)
         out = log.read().decode(errors="replace")
     assert "Test error" not in out, out[-800:]
     assert rc in (None, 0), (rc, out[-800:])
-    assert out.count("done") > 20000, "the test did not get far enough: " + out[-500:]
+    assert out.count("done") > 10000, "the test did not get far enough: " + out[-500:]
 
 
 @pytest.mark.parametrize("distribution,bytesoftype", [("sorted", 4), ("random", 2), ("random", 8), ("sorted", 7), ("random", 1), ("same", 12)])
@@ -53,14 +53,14 @@ def test_the_references_round_trip_test_by_distribution(distribution, bytesoftyp
 
     with tempfile.TemporaryFile() as log:
         try:
-            rc = subprocess.run([_binary("ref_tests_shard"), distribution, str(bytesoftype)], stdout=log, stderr=subprocess.STDOUT, timeout=40).returncode
+            rc = subprocess.run([_binary("ref_tests_shard"), distribution, str(bytesoftype)], stdout=log, stderr=subprocess.STDOUT, timeout=25).returncode
         except subprocess.TimeoutExpired:
             rc = None
         log.seek(0)
         out = log.read().decode(errors="replace")
     assert "Test error" not in out, out[-800:]
     assert rc in (None, 0), (rc, out[-800:])
-    assert out.count("done") > 1000, "the cell did not get far enough: " + out[-500:]
+    assert out.count("done") > 500, "the cell did not get far enough: " + out[-500:]
 
 
 def test_the_references_cvector_test_links_and_runs_against_this_library():
