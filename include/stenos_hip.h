@@ -88,8 +88,9 @@ STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_
 STENOS_EXPORT int stenos_hip_stage_ms(stenos_context* ctx, double* out, int n, int reset);
 
 /* Tests only: serial != 0 makes frames that come without an index be walked by one lane (the serial walk that the
- * parallel one of walk.h is proven against, and falls back to). */
-STENOS_EXPORT void stenos_hip_test_walk(stenos_context* ctx, int serial);
+ * parallel one of walk.h is proven against, and falls back to).  Returns whether the last parallel walk on ctx fell back
+ * to the serial one (1), did not (0), or there was none (-1). */
+STENOS_EXPORT int stenos_hip_test_walk(stenos_context* ctx, int serial);
 
 /* The fused encoder's waits for frame offsets are bounded; a launch that gives up (never observed) is redone without that
  * kernel instead of failing the call.  Returns how often that has happened on ctx.  inject > 0 (tests): the next

@@ -77,7 +77,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "stenos_hip_last_devices": (c_int, [vp]),
         "stenos_hip_set_devices": (None, [vp, c_int]),
         "stenos_hip_test_lanes": (None, [vp, c_int, c_int]),
-        "stenos_hip_test_walk": (None, [vp, c_int]),
+        "stenos_hip_test_walk": (c_int, [vp, c_int]),
         "stenos_hip_stage_ms": (c_int, [vp, ctypes.POINTER(ctypes.c_double), c_int, c_int]),
         "stenos_hip_fused_fallbacks": (c_int, [vp, c_int]),
         "stenos_hip_workspace_bytes": (sz, [sz, sz]),

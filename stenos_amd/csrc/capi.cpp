@@ -2489,10 +2489,17 @@ int stenos_hip_stage_ms(stenos_context* ctx, double* out, int n, int reset)
 			v = 0;
 	return (int)STAGE_COUNT;
 }
-void stenos_hip_test_walk(stenos_context* ctx, int serial)
+int stenos_hip_test_walk(stenos_context* ctx, int serial)
 {
-	if (ctx)
-		ctx->test_serial_walk = serial != 0;
+	if (!ctx)
+		return -1;
+	int fell_back = -1; // the flag word the last parallel walk left in its scratch (walk_kernels.hip): 1 = the serial walk ran after all
+	uint32_t flags = 0;
+	if (!ctx->test_serial_walk && ctx->walk.p && ctx->device_ready() && hipDeviceSynchronize() == hipSuccess &&
+	    hipMemcpy(&flags, ctx->walk.p, 4, hipMemcpyDeviceToHost) == hipSuccess)
+		fell_back = flags != 0;
+	ctx->test_serial_walk = serial != 0;
+	return fell_back;
 }
 void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane)
 {

@@ -43,7 +43,7 @@ namespace walk {
 constexpr uint32_t MAX_SEGMENTS = STENOS_WALK_MAX_SEGMENTS;
 constexpr uint32_t LANES = 64;
 constexpr uint32_t MIN_SEGMENTS = 4;       // below, the serial walk
-constexpr uint32_t SEG_WINDOWS = STENOS_WALK_SEG_WINDOWS; // a segment is at least this many windows long
+constexpr uint32_t SEG_WINDOWS = STENOS_WALK_SEG_WINDOWS; // a segment is at most this many windows long, unless the frame needs more than MAX_SEGMENTS of them
 constexpr uint32_t PROOF_HOPS = 2;         // plausible headers a speculated chain must meet behind its segment
 enum : uint32_t { SEG_UNRESOLVED = 0, SEG_OK = 1 };
 enum : uint32_t { WALK_FAILED = 1 };
@@ -81,6 +81,10 @@ inline Plan make_plan(uint64_t first, uint64_t size, uint64_t nsb, uint32_t sb_b
 	if (size <= first || nsb < 2 * MIN_SEGMENTS)
 		return P;
 	const uint64_t span = size - first;
+	// Segment length: a few windows.  (One window per segment would suit frames of small payloads -- sorted keys: 2 KB per
+	// 128 KiB superblock, 230 serial hops per segment in phases B and C -- but then a false chain only has to survive a hop or
+	// two, and structured payloads hold enough header look-alikes for several to survive with different exits: measured, the
+	// 8 GiB sorted frame then falls back to the serial walk.)
 	uint64_t len = seg_len_override ? seg_len_override : (uint64_t)P.window * SEG_WINDOWS;
 	if (len < P.window)
 		len = P.window;
@@ -123,7 +127,19 @@ WALK_HD void scan_window16(const Plan& P, const uint8_t* frame, uint32_t k, uint
 			}
 		}
 	}
-	for (uint32_t j = 0; j < 16; ++j) {
+	// First a filter on the sixteen code bytes at once: a byte b is a candidate when b - 1 < 8 (codes 1..6 and two more:
+	// the price of doing it on four bytes per instruction); 3 % of the bytes of a payload pass and get the full test.
+	uint32_t cand = 0;
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t y = (w[i] | 0x80808080u) - 0x01010101u;                   // per byte (b - 1) mod 128, no borrow between bytes
+		const uint32_t z = (y & 0x78787878u) | (w[i] & 0x80808080u);             // zero byte: b in 1..8
+		const uint32_t nz = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;               // bit 7 of every byte: the byte is not zero
+		const uint32_t f = ~nz & 0x80808080u;
+		cand |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * i);
+	}
+	while (cand) {
+		const uint32_t j = (uint32_t)__builtin_ctz(cand);
+		cand &= cand - 1u;
 		const uint64_t p = base + j;
 		if (p >= wend || !readable(P, p))
 			break;

@@ -23,7 +23,7 @@ def _index(st, frame, T, csize, serial):
         st.lib.stenos_hip_test_walk(st.ctx, 0)
 
 
-@pytest.mark.parametrize("kind,T,mib", [("rand12", 4, 300), ("rand", 4, 64), ("sorted_i32", 4, 512), ("walk", 2, 200), ("sine", 8, 100), ("sine", 4, 90), ("rand8", 2, 33)])
+@pytest.mark.parametrize("kind,T,mib", [("rand12", 4, 300), ("rand", 4, 64), ("sorted_i32", 4, 512), ("sorted_i32", 4, 3000), ("walk", 2, 200), ("sine", 8, 100), ("sine", 4, 90), ("rand8", 2, 33)])
 def test_parallel_walk_equals_serial_walk_and_encoder_index(kind, T, mib):
     n = (mib << 20) // T + 4321
     src = generate_torch(kind, T, n, 17)
@@ -37,8 +37,10 @@ def test_parallel_walk_equals_serial_walk_and_encoder_index(kind, T, mib):
     hip = ctypes.CDLL("libamdhip64.so")
     assert hip.hipMemcpy(ctypes.c_void_p(enc.data_ptr()), ctypes.c_void_p(p), ctypes.c_size_t((nsb + 1) * 8), 2) == 0
     par = _index(st, dst, T, c, serial=False)
+    fell_back = st.lib.stenos_hip_test_walk(st.ctx, 0)
     ser = _index(st, dst, T, c, serial=True)
     assert par is not None and par == ser
+    assert fell_back == 0, "a well-formed frame needed the serial walk"
     assert par == enc.tolist()
     # frame-only decode: no index handed over
     back = torch.zeros_like(src)
