@@ -199,6 +199,13 @@ WV_FN U32 mul24(const U32& a, const U32& b)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (a.l[i] & 0xFFFFFFu) * (b.l[i] & 0xFFFFFFu);
 	return r;
 }
+// v_mad_u32_u24: a * b + c, the low 24 bits of a and b
+WV_FN U32 mad24(const U32& a, const U32& b, const U32& c)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (a.l[i] & 0xFFFFFFu) * (b.l[i] & 0xFFFFFFu) + c.l[i];
+	return r;
+}
 // v_perm_b32: result byte i = byte (sel byte i) of the 8 bytes {hi:lo}; selector 0x0c gives 0
 WV_FN U32 perm_bytes(const U32& hi, const U32& lo, uint32_t selw)
 {
@@ -292,6 +299,13 @@ WV_FN U32 row_shr(const U32& a, uint32_t n, uint32_t fill)
 {
 	U32 r;
 	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)(i & 15) >= n ? a.l[i - (int)n] : fill;
+	return r;
+}
+// every lane reads the last lane of its group of 4
+WV_FN U32 quad_last(const U32& a)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = a.l[i | 3];
 	return r;
 }
 WV_FN void wave_sync() {}
@@ -553,6 +567,7 @@ WV_FN U32 pk_max_u16(U32 a, U32 b) { return __builtin_bit_cast(U32, __builtin_el
 WV_FN U32 bitlen(U32 a) { return a ? 32u - (U32)__builtin_clz(a) : 0u; }
 WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 mul24(U32 a, U32 b) { return __umul24(a, b); } // low 24 bits of both operands, full rate
+WV_FN U32 mad24(U32 a, U32 b, U32 c) { return __umul24(a, b) + c; } // (one v_mad_u32_u24)
 WV_FN U32 dot4_u8(U32 a, uint32_t b, U32 c) { return __builtin_amdgcn_udot4(a, b, c, false); } // c + sum of the four byte products
 WV_FN U32 bfe(U32 x, U32 off, U32 width) { return __builtin_amdgcn_ubfe(x, off, width); }
 WV_FN U32 funnel_shr(U32 hi, U32 lo, U32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
@@ -646,6 +661,7 @@ WV_FN U32 row_shr(U32 a, uint32_t n, uint32_t fill)
 		default: return (U32)__builtin_amdgcn_update_dpp((int)fill, (int)a, 0x118, 0xf, 0xf, false);
 	}
 }
+WV_FN U32 quad_last(U32 a) { return (U32)__builtin_amdgcn_update_dpp(0, (int)a, 0xFF, 0xf, 0xf, false); } // quad_perm:[3,3,3,3]
 // lanes 16k .. 16k+15 receive a_k (four uniform values): four moves under narrowing execution masks, no compare
 WV_FN U32 row_select4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
 {
@@ -1114,7 +1130,9 @@ WV_FN void lanes_below(uint32_t n, F f)
 // byte 0 of x in all four bytes (one v_perm_b32)
 WV_FN U32 splat_byte0(const U32& x) { return perm_bytes(x, x, 0u); }
 
-// unaligned little-endian 32-bit read from LDS (two aligned reads + funnel)
+// unaligned little-endian 32-bit read from LDS (two aligned reads + funnel).  gfx950 does serve a ds_read_b32 of any byte
+// address and the compiler emits it for a load of alignment 1, but it is far slower than this: the int16 decoder went
+// from 3.57 to 5.8 ms per 8 GiB with it (measured, round 4).
 WV_FN U32 lds_ld32_unaligned(Lds m, const U32& a)
 {
 	U32 lo, hi;
@@ -1309,6 +1327,23 @@ WV_FN U32 quads_excl_scan(const U32& x)
 	return s - x;
 }
 
+// the inclusive forms, sum and maximum (values of a quad equal in its four lanes)
+WV_FN U32 quads_incl_scan(const U32& x)
+{
+	U32 s = x;
+	s = s + scan_source(s, 2, 0);
+	s = s + scan_source(s, 3, 0);
+	s = s + scan_source(s, 4, 0);
+	return s + scan_source(s, 5, 0);
+}
+WV_FN U32 quads_incl_scan_max(const U32& x)
+{
+	U32 s = x;
+	s = umax(s, scan_source(s, 2, 0));
+	s = umax(s, scan_source(s, 3, 0));
+	s = umax(s, scan_source(s, 4, 0));
+	return umax(s, scan_source(s, 5, 0));
+}
 // ---- SWAR on four packed bytes ----
 WV_FN U32 bytes_sub(const U32& a, const U32& b) // per-byte a - b (mod 256)
 {
