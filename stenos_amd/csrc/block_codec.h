@@ -1103,44 +1103,55 @@ WV_FN void dec_write_lut(Lds lds, const DecLayout& L)
 	lds_st32(lds, U32(L.lut) + lane * 4u, pat, lane < U32(16u));
 	wave_sync();
 }
-// A plane of a full block whose sixteen rows are all bit-packed (no run-length row, no raw row: the usual shape), given its
-// row headers: every row has a minimum and (hdr & 7) * 2 payload bytes, and it is absolute (hdr < 8) or made of
-// differences (hdr >= 8, block_compress.h:1650-1700).  Same result as the general form below, in fewer instructions:
-//  - one scan over the rows (payload offsets); the minimums lie one per row;
+// A plane of a full block without run-length rows (the usual shape), given its row headers: a row is bit-packed -- a
+// minimum and (hdr & 7) * 2 payload bytes, absolute (hdr < 8) or made of differences (hdr >= 8) -- or raw (hdr 15: sixteen
+// bytes, here an absolute row of 8-bit values with minimum 0) (block_compress.h:1650-1700).  Same result as the general
+// form below, in fewer instructions:
+//  - one scan over the rows (payload offsets, and the position of the row's minimum where raw rows have none);
 //  - the lane's four values stay in four registers: absolute lanes pack them, difference lanes add them up on the way;
 //  - the carry into a difference lane = last value of the nearest absolute row before it + the differences in between:
 //    one prefix sum over the lanes, and for the absolute rows a key (row + 1) << 8 | (last value - prefix there) whose
 //    running maximum over the rows (four steps) hands every later row the newest one.
 //    No gather through the LDS crossbar.  Where only row 0 is absolute (or none), its last value is one readlane.
-WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, const U32& hdr, U32* keep)
+WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, const U32& hdr, bool has_raw, U32* keep)
 {
 	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
 	const U32 row = lane >> 2, q = lane & 3u;
-	uint32_t minslen;
-	U32 minv;
-	if (type == PLANE_NORMAL) {
-		minslen = 16;
-		minv = lds_ld8(win, U32(cur + 8) + row);
+	U32 bits = hdr & 7u, m = hdr >> 3; // m = 1: a row of differences
+	U32 bytes = bits + bits;
+	U32 upto, minv, minat = row;
+	uint32_t minslen = 16;
+	if (has_raw) {
+		const U32 raw = (hdr + 1u) >> 4;
+		bits = bits + raw;
+		bytes = bits + bits;
+		m = m ^ raw;
+		const U32 both = quads_incl_scan(bytes | ((raw ^ 1u) << 16)); // rows with a minimum, counted in the upper half
+		upto = both & 0xFFFFu;
+		minat = (both >> 16) - (raw ^ 1u);
+		minslen = readlane(both, 63) >> 16;
 	}
-	else { // NORMAL_RLE: mask16, then the minimums that differ from the one before
+	else
+		upto = quads_incl_scan(bytes);
+	if (type == PLANE_NORMAL)
+		minv = lds_ld8(win, U32(cur + 8) + minat);
+	else { // NORMAL_RLE: mask16, then the minimums that differ from the one before (a raw row has one as well here)
 		const uint32_t mask = readlane(lds_ld32_unaligned(win, U32(cur + 8)), 0) & 0xFFFFu;
 		minslen = 2 + 16 - (uint32_t)__builtin_popcount(mask);
 		U32 idx = popc((~U32(mask)) & ((U32(2u) << row) - 1u) & 0xFFFFu);
 		minv = sel(idx == U32(0u), U32(0u), lds_ld8(win, U32(cur + 10) + sel(idx == U32(0u), U32(0u), idx - 1u)));
 	}
-	const U32 bits = hdr & 7u;
-	const U32 bytes = bits + bits;
-	const U32 upto = quads_incl_scan(bytes);
-	const uint32_t psize = 8 + minslen + readlane(upto, 63);
+	if (has_raw)
+		minv = minv & ((bits >> 3) - 1u); // (no minimum is added to a raw row)
+	const uint32_t psize = 8 + minslen + (readlane(upto, 63) & 0xFFFFu);
 	// the lane's four values: 4 * bits bits from bit q * 4 * bits of the row's payload on
 	const U32 t = mul24(q, bits);
 	const U32 px = lds_ld32_unaligned(win, U32(cur + 8 + minslen) + (upto - bytes) + (t >> 1)) >> ((t & 1u) << 2);
 	const U32 v0 = bfe(px, U32(0u), bits) + minv, v1 = bfe(px, bits, bits) + minv, v2 = bfe(px, bytes, bits) + minv, v3 = bfe(px, bytes + bits, bits) + minv;
 	U32 o0 = v0, o1 = v1, o2 = v2, o3 = v3;
-	const uint64_t diff_rows = ballot(hdr >= U32(8u));
+	const uint64_t diff_rows = ballot(m != U32(0u));
 	if (diff_rows) {
-		const U32 m = hdr >> 3; // 1: a row of differences
 		// running sums inside the lane: difference lanes add up, absolute lanes keep their values (m = 0)
 		o1 = mad24(m, o0, v1);
 		o2 = mad24(m, o1, v2);
@@ -1152,7 +1163,7 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 			K = U32((diff_rows & 1u) ? 0u : readlane(o3, 3));
 		else {
 			const U32 last = quad_last(o3);
-			const U32 key = sel(hdr >= U32(8u), U32(0u), ((row + 1u) << 8) | ((last - P) & 0xFFu));
+			const U32 key = sel(m != U32(0u), U32(0u), ((row + 1u) << 8) | ((last - P) & 0xFFu));
 			K = quads_incl_scan_max(key);
 		}
 		const U32 carry = mul24(m, (K + P) - S); // (its low byte counts; 0 in absolute rows)
@@ -1187,8 +1198,8 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 hdr, minv;
 	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
 #ifndef STENOS_DECODE_NO_PACKED_PATH
-	if (lines == 16 && ballot(((hdr & 0xEu) == U32(6u)) | (hdr == U32(15u))) == 0)
-		return decode_plane_packed(lds, L, T, j, type, cur, hdr, keep);
+	if (lines == 16 && ballot((hdr & 0xEu) == U32(6u)) == 0)
+		return decode_plane_packed(lds, L, T, j, type, cur, hdr, ballot(hdr == U32(15u)) != 0, keep);
 #endif
 	if (type == PLANE_NORMAL) {
 		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));
