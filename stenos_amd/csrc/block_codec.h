@@ -1073,17 +1073,23 @@ WV_FN U32 chain_carry(const U32& A, const U32& Bw, uint32_t seg_mask)
 	const U32 lane = lane_id_plain();
 	// the lane's own function: value of its last byte for carry-in 0, and whether the carry goes through
 	U32 last = chain_apply(A, Bw, U32(0u)) >> 24;
-	U32 f = (sel((A & 0xFu) == U32(0xFu), U32(1u), U32(0u)) << 8) | last;
+	const Pred through = (A & 0xFu) == U32(0xFu);
+	if (seg_mask == 63) {
+		// Whole wave.  A lane either hands its carry on plus a constant (all four flags set) or ends with a value of its own.
+		// The value behind lane l = that of the nearest lane of the second kind up to l + the constants behind it: one prefix sum
+		// of the constants, and a running maximum of keys (lane + 1) << 8 | (own value - prefix there) that hands every lane the
+		// newest such lane -- twelve DPP steps of one instruction each instead of six rounds of function composition.
+		const U32 P = wave_incl_scan(sel(through, last, U32(0u)));
+		const U32 K = wave_incl_scan_max(sel(through, U32(0u), ((lane + 1u) << 8) | ((last - P) & 0xFFu)));
+		return shfl_up(K + P, 1, 0) & 0xFFu;
+	}
+	U32 f = (sel(through, U32(1u), U32(0u)) << 8) | last;
 	const U32 ident(1u << 8);
-	if (seg_mask == 63) // whole wave: the DPP scan pattern (no LDS crossbar)
-		for (int step = 0; step < 6; ++step)
-			f = chain_compose(scan_source(f, step, 1u << 8), f);
-	else { // inside the segments (quads: seg_mask 3): the row shifts, cut at the segment starts
-		int step = 0;
-		for (uint32_t d = 1; d <= seg_mask; d <<= 1, ++step) {
-			U32 prev = sel((lane & U32(seg_mask)) >= U32(d), scan_source(f, step, 1u << 8), ident);
-			f = chain_compose(prev, f);
-		}
+	// inside the segments (quads: seg_mask 3): the row shifts, cut at the segment starts
+	int step = 0;
+	for (uint32_t d = 1; d <= seg_mask; d <<= 1, ++step) {
+		U32 prev = sel((lane & U32(seg_mask)) >= U32(d), scan_source(f, step, 1u << 8), ident);
+		f = chain_compose(prev, f);
 	}
 	U32 ex = shfl_up(f, 1, 1u << 8);
 	ex = sel((lane & U32(seg_mask)) == U32(0u), ident, ex);
