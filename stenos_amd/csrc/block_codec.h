@@ -1119,17 +1119,20 @@ WV_FN void dec_write_lut(Lds lds, const DecLayout& L)
 //    one prefix sum over the lanes, and for the absolute rows a key (row + 1) << 8 | (last value - prefix there) whose
 //    running maximum over the rows (four steps) hands every later row the newest one.
 //    No gather through the LDS crossbar.  Where only row 0 is absolute (or none), its last value is one readlane.
-WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, const U32& hdr, bool has_raw, U32* keep)
+template <bool has_raw> // (two copies: merged, the compiler turns the raw rows' extras into selects that every plane pays)
+WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, const U32& hdr, U32* keep)
 {
 	const U32 lane = lane_id_plain();
 	Lds win = lds + L.win;
 	const U32 row = lane >> 2, q = lane & 3u;
 	U32 bits = hdr & 7u, m = hdr >> 3; // m = 1: a row of differences
 	U32 bytes = bits + bits;
-	U32 upto, minv, minat = row;
+	U32 upto, minv, minat = row, nomin(~0u);
 	uint32_t minslen = 16;
 	if (has_raw) {
+		WV_NESTED();
 		const U32 raw = (hdr + 1u) >> 4;
+		nomin = raw - 1u; // (no minimum is added to a raw row)
 		bits = bits + raw;
 		bytes = bits + bits;
 		m = m ^ raw;
@@ -1146,14 +1149,13 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		const uint32_t mask = readlane(lds_ld32_unaligned(win, U32(cur + 8)), 0) & 0xFFFFu;
 		minslen = 2 + 16 - (uint32_t)__builtin_popcount(mask);
 		U32 idx = popc((~U32(mask)) & ((U32(2u) << row) - 1u) & 0xFFFFu);
-		minv = sel(idx == U32(0u), U32(0u), lds_ld8(win, U32(cur + 10) + sel(idx == U32(0u), U32(0u), idx - 1u)));
+		minv = sel(idx == U32(0u), U32(0u), lds_ld8(win, U32(cur + 9) + idx)); // (idx 0 reads the mask's second byte and drops it)
 	}
 	if (has_raw)
-		minv = minv & ((bits >> 3) - 1u); // (no minimum is added to a raw row)
+		minv = minv & nomin;
 	const uint32_t psize = 8 + minslen + (readlane(upto, 63) & 0xFFFFu);
 	// the lane's four values: 4 * bits bits from bit q * 4 * bits of the row's payload on
-	const U32 t = mul24(q, bits);
-	const U32 px = lds_ld32_unaligned(win, U32(cur + 8 + minslen) + (upto - bytes) + (t >> 1)) >> ((t & 1u) << 2);
+	const U32 px = lds_ld32_bits(win, ((U32(cur + 8 + minslen) + (upto - bytes)) << 3) + (mul24(q, bits) << 2));
 	const U32 v0 = bfe(px, U32(0u), bits) + minv, v1 = bfe(px, bits, bits) + minv, v2 = bfe(px, bytes, bits) + minv, v3 = bfe(px, bytes + bits, bits) + minv;
 	U32 o0 = v0, o1 = v1, o2 = v2, o3 = v3;
 	const uint64_t diff_rows = ballot(m != U32(0u));
@@ -1180,6 +1182,11 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		*keep = outw;
 	else
 		store_plane_word(lds, L.img, T, j, outw, pred_all(true));
+	// (no code: two different last statements keep the compiler from folding the tails of the two copies into one again)
+	if (has_raw)
+		WV_MARK("dec_packed_raw_end");
+	else
+		WV_MARK("dec_packed_end");
 	return psize;
 }
 
@@ -1204,8 +1211,11 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 hdr, minv;
 	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
 #ifndef STENOS_DECODE_NO_PACKED_PATH
-	if (lines == 16 && ballot((hdr & 0xEu) == U32(6u)) == 0)
-		return decode_plane_packed(lds, L, T, j, type, cur, hdr, ballot(hdr == U32(15u)) != 0, keep);
+	if (lines == 16 && ballot((hdr & 0xEu) == U32(6u)) == 0) {
+		if (ballot(hdr == U32(15u)) != 0)
+			return decode_plane_packed<true>(lds, L, T, j, type, cur, hdr, keep);
+		return decode_plane_packed<false>(lds, L, T, j, type, cur, hdr, keep);
+	}
 #endif
 	if (type == PLANE_NORMAL) {
 		Pred emit = act & (hdr != U32(6u)) & (hdr != U32(7u)) & (hdr != U32(15u));

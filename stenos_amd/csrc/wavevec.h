@@ -703,11 +703,14 @@ WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
 }
 #else
 WV_FN U32 lds_ld8(Lds m, U32 a) { return m[a]; }
-WV_FN U32 lds_ld32(Lds m, U32 a) { return *(const uint32_t*)(m + (a & ~3u)); }
+// (the address is aligned down after the base is added: the scratch starts at a multiple of 16, and that way the addition
+// joins the scalar arithmetic of a wave-uniform part of `a` instead of costing a vector instruction behind the v_and)
+WV_FN U32 lds_ld32(Lds m, U32 a) { return *(const uint32_t*)__builtin_align_down(m + a, 4); }
 WV_FN void lds_ld64(Lds m, U32 a, U32& lo, U32& hi)
 {
-	lo = *(const uint32_t*)(m + (a & ~3u));
-	hi = *(const uint32_t*)(m + (a & ~3u) + 4);
+	const uint32_t* p = (const uint32_t*)__builtin_align_down(m + a, 4);
+	lo = p[0];
+	hi = p[1];
 }
 #endif
 // Predicated memory accesses without a branch.  `if (p) store` is a divergent branch, and with one divergent branch
@@ -1138,6 +1141,14 @@ WV_FN U32 lds_ld32_unaligned(Lds m, const U32& a)
 	U32 lo, hi;
 	lds_ld64(m, a, lo, hi); // reads the aligned dword containing a and the next one
 	return funnel_shr(hi, lo, (a & 3u) << 3); // (hi:lo) >> 0, 8, 16 or 24: one v_alignbit_b32, no case for the aligned address
+}
+
+// 32 bits of the LDS bit stream (LSB first) from bit position bitpos on: the two aligned dwords around it, one funnel shift
+WV_FN U32 lds_ld32_bits(Lds m, const U32& bitpos)
+{
+	U32 lo, hi;
+	lds_ld64(m, bitpos >> 3, lo, hi);
+	return funnel_shr(hi, lo, bitpos); // (v_alignbit_b32 takes the low five bits: 8 * (byte address & 3) + bitpos & 7)
 }
 
 // OR `nbits` (<= 32) bits of value into the LDS bit stream at bit position bitpos (LSB first);
