@@ -1097,16 +1097,21 @@ WV_FN U32 chain_carry(const U32& A, const U32& Bw, uint32_t seg_mask)
 }
 
 // Entry f of the selector table: byte k of the result = flag bit k of f ? 0 : the next literal.  Lane f writes entry f.
+// Behind it a second table of 32 entries for rows of run-length coded differences (decode_plane_packed): entry f
+// (+ 16: no literal in front of the lane), byte k = pool byte [number of clear flags among bits 0..k of f], where pool byte 0
+// is the literal in force when the lane begins (entries 16..31: zero instead, selector 0x0c).
 WV_FN void dec_write_lut(Lds lds, const DecLayout& L)
 {
 	const U32 lane = lane_id_plain();
-	U32 pat(0u), n(0u);
+	U32 pat(0u), n(0u), pat2(0u);
 	for (uint32_t k = 0; k < 4; ++k) {
 		const Pred lit = ((lane >> k) & 1u) == U32(0u);
 		pat = pat | (sel(lit, n, U32(0x0cu)) << U32(8u * k));
 		n = n + sel(lit, U32(1u), U32(0u));
+		pat2 = pat2 | (sel((n == U32(0u)) & (lane >= U32(16u)), U32(0x0cu), n) << U32(8u * k));
 	}
 	lds_st32(lds, U32(L.lut) + lane * 4u, pat, lane < U32(16u));
+	lds_st32(lds, U32(L.lut + 64) + lane * 4u, pat2, lane < U32(32u));
 	wave_sync();
 }
 // A plane of a full block without run-length rows (the usual shape), given its row headers: a row is bit-packed -- a
@@ -1119,7 +1124,13 @@ WV_FN void dec_write_lut(Lds lds, const DecLayout& L)
 //    one prefix sum over the lanes, and for the absolute rows a key (row + 1) << 8 | (last value - prefix there) whose
 //    running maximum over the rows (four steps) hands every later row the newest one.
 //    No gather through the LDS crossbar.  Where only row 0 is absolute (or none), its last value is one readlane.
-template <bool has_raw> // (two copies: merged, the compiler turns the raw rows' extras into selects that every plane pays)
+// has_rle: rows of run-length coded differences (hdr 6: mask16 + the differences that are not repeats, block_compress.h:
+// 1678-1690) among them.  Their sizes come from their masks, read row by row as in the general form; then such a row is a
+// row of differences with 8-bit values and no minimum, and a lane finds its four by position: the difference in force when
+// the lane begins is the literal in front of its own ones (none: 0), so the five bytes from there on and a table entry for
+// the lane's four flags (dec_write_lut: byte k = pool byte [number of clear flags up to k]) are one v_perm_b32.  No chain.
+// (Three copies -- plain, raw rows, raw and run-length rows: merged, the compiler turns the extras into selects that every plane pays.)
+template <bool has_raw, bool has_rle>
 WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, const U32& hdr, U32* keep)
 {
 	const U32 lane = lane_id_plain();
@@ -1127,25 +1138,32 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 	const U32 row = lane >> 2, q = lane & 3u;
 	U32 bits = hdr & 7u, m = hdr >> 3; // m = 1: a row of differences
 	U32 bytes = bits + bits;
-	U32 upto, minv, minat = row, nomin(~0u);
-	uint32_t minslen = 16;
+	U32 upto, minv, minat = row, nomin(~0u), rowoff, rmask(0u);
+	uint32_t minslen = 16, rle_total = 0;
+	Pred isr = pred_all(false);
 	if (has_raw) {
 		WV_NESTED();
-		const U32 raw = (hdr + 1u) >> 4;
-		nomin = raw - 1u; // (no minimum is added to a raw row)
+		U32 raw = (hdr + 1u) >> 4, plain = raw ^ 1u;
 		bits = bits + raw;
-		bytes = bits + bits;
 		m = m ^ raw;
-		const U32 both = quads_incl_scan(bytes | ((raw ^ 1u) << 16)); // rows with a minimum, counted in the upper half
+		if (has_rle) {
+			isr = hdr == U32(6u);
+			plain = sel(isr, U32(0u), plain);
+			bits = sel(isr, U32(0u), bits); // (no payload of known size: see below)
+			m = sel(isr, U32(1u), m);
+		}
+		nomin = U32(0u) - plain; // (no minimum is added to a raw row or a run-length row)
+		bytes = bits + bits;
+		const U32 both = quads_incl_scan(bytes | (plain << 16)); // rows with a minimum, counted in the upper half
 		upto = both & 0xFFFFu;
-		minat = (both >> 16) - (raw ^ 1u);
+		minat = (both >> 16) - plain;
 		minslen = readlane(both, 63) >> 16;
 	}
 	else
 		upto = quads_incl_scan(bytes);
 	if (type == PLANE_NORMAL)
 		minv = lds_ld8(win, U32(cur + 8) + minat);
-	else { // NORMAL_RLE: mask16, then the minimums that differ from the one before (a raw row has one as well here)
+	else { // NORMAL_RLE: mask16, then the minimums that differ from the one before (every row has one here)
 		const uint32_t mask = readlane(lds_ld32_unaligned(win, U32(cur + 8)), 0) & 0xFFFFu;
 		minslen = 2 + 16 - (uint32_t)__builtin_popcount(mask);
 		U32 idx = popc((~U32(mask)) & ((U32(2u) << row) - 1u) & 0xFFFFu);
@@ -1153,9 +1171,39 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 	}
 	if (has_raw)
 		minv = minv & nomin;
-	const uint32_t psize = 8 + minslen + (readlane(upto, 63) & 0xFFFFu);
+	rowoff = U32(cur + 8 + minslen) + (upto - bytes);
+	if (has_rle) {
+		WV_NESTED();
+		uint64_t todo = ballot(isr) & 0x1111111111111111ull; // one bit per row: that of its first lane
+		U32 extra(0u);
+		while (todo) {
+			const uint32_t rl = (uint32_t)__builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint32_t mk = win_u16(win, readlane(rowoff + extra, rl));
+			const uint32_t sz = 2 + 16 - (uint32_t)__builtin_popcount(mk);
+			rmask = sel(row == U32(rl >> 2), U32(mk), rmask);
+			extra = extra + sel(row > U32(rl >> 2), U32(sz), U32(0u));
+			rle_total += sz;
+		}
+		rowoff = rowoff + extra;
+	}
+	const uint32_t psize = 8 + minslen + (readlane(upto, 63) & 0xFFFFu) + rle_total;
 	// the lane's four values: 4 * bits bits from bit q * 4 * bits of the row's payload on
-	const U32 px = lds_ld32_bits(win, ((U32(cur + 8 + minslen) + (upto - bytes)) << 3) + (mul24(q, bits) << 2));
+	U32 px = lds_ld32_bits(win, (rowoff << 3) + (mul24(q, bits) << 2));
+	if (has_rle) {
+		WV_NESTED();
+		const U32 shift = q << 2;
+		const U32 f = (rmask >> shift) & 0xFu;
+		const U32 before = popc(~rmask & ((U32(1u) << shift) - 1u)); // literals of the row in front of this lane's
+		const U32 at = rowoff + 1u + before;                         // the last of them (none: a byte of the mask, not used)
+		U32 lo, hi;
+		lds_ld64(win, at, lo, hi);
+		const U32 pool_lo = funnel_shr(hi, lo, at << 3), pool_hi = hi >> ((at & 3u) << 3);
+		const U32 selw = lds_ld32(lds, U32(L.lut + 64) + ((f | sel(before == U32(0u), U32(16u), U32(0u))) << 2));
+		px = sel(isr, perm_bytes_v(pool_hi, pool_lo, selw), px);
+		bits = sel(isr, U32(8u), bits);
+		bytes = bits + bits;
+	}
 	const U32 v0 = bfe(px, U32(0u), bits) + minv, v1 = bfe(px, bits, bits) + minv, v2 = bfe(px, bytes, bits) + minv, v3 = bfe(px, bytes + bits, bits) + minv;
 	U32 o0 = v0, o1 = v1, o2 = v2, o3 = v3;
 	const uint64_t diff_rows = ballot(m != U32(0u));
@@ -1182,8 +1230,10 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		*keep = outw;
 	else
 		store_plane_word(lds, L.img, T, j, outw, pred_all(true));
-	// (no code: two different last statements keep the compiler from folding the tails of the two copies into one again)
-	if (has_raw)
+	// (no code: different last statements keep the compiler from folding the tails of the copies into one again)
+	if (has_rle)
+		WV_MARK("dec_packed_rle_end");
+	else if (has_raw)
 		WV_MARK("dec_packed_raw_end");
 	else
 		WV_MARK("dec_packed_end");
@@ -1211,10 +1261,12 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 hdr, minv;
 	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
 #ifndef STENOS_DECODE_NO_PACKED_PATH
-	if (lines == 16 && ballot((hdr & 0xEu) == U32(6u)) == 0) {
+	if (lines == 16 && ballot(hdr == U32(7u)) == 0) {
+		if (ballot(hdr == U32(6u)) != 0)
+			return decode_plane_packed<true, true>(lds, L, T, j, type, cur, hdr, keep);
 		if (ballot(hdr == U32(15u)) != 0)
-			return decode_plane_packed<true>(lds, L, T, j, type, cur, hdr, keep);
-		return decode_plane_packed<false>(lds, L, T, j, type, cur, hdr, keep);
+			return decode_plane_packed<true, false>(lds, L, T, j, type, cur, hdr, keep);
+		return decode_plane_packed<false, false>(lds, L, T, j, type, cur, hdr, keep);
 	}
 #endif
 	if (type == PLANE_NORMAL) {

@@ -654,7 +654,7 @@ WV_HD DecLayout make_dec_layout(uint32_t T)
 	L.img = window_bytes(T) + 32;
 	const uint32_t after = 256 * T + 32;
 	L.lut = align16(L.img + (after > max_block_reach(T) ? after : max_block_reach(T)));
-	L.total = L.lut + 64;
+	L.total = L.lut + 64 + 128; // (the two tables of dec_write_lut)
 	return L;
 }
 
