@@ -1487,7 +1487,7 @@ WV_FN uint32_t decode_planes_to(Lds lds, const DecLayout& L, uint32_t cur, uint3
 			p += 1;
 		}
 		else { // RAW (:1553-1565)
-			w[j] = lds_ld32_unaligned(win, U32(p) + lane * 4u);
+			w[j] = lds_ld32_run(win, p, lane * 4u);
 			p += 256;
 		}
 	}
@@ -1547,7 +1547,7 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 			if (avail < 1 + 256 * T)
 				return DEC_ERROR;
 			for (uint32_t o = 0; o < 256 * T; o += 256) {
-				U32 v = lds_ld32_unaligned(win, U32(cur + 1 + o) + lane * 4u);
+				U32 v = lds_ld32_run(win, cur + 1 + o, lane * 4u);
 				lds_st32(lds, U32(L.img + o) + lane * 4u, v, pred_all(true));
 			}
 			wave_sync();

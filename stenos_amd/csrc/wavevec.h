@@ -1143,6 +1143,14 @@ WV_FN U32 lds_ld32_unaligned(Lds m, const U32& a)
 	return funnel_shr(hi, lo, (a & 3u) << 3); // (hi:lo) >> 0, 8, 16 or 24: one v_alignbit_b32, no case for the aligned address
 }
 
+// the lane's dword of a run of dwords that starts at the wave-uniform byte address a: lane l reads a + 4 * l.  The
+// misalignment is the same in all lanes, so it stays in scalar registers: one vector addition and the funnel shift.
+WV_FN U32 lds_ld32_run(Lds m, uint32_t a, const U32& lane4)
+{
+	U32 lo, hi;
+	lds_ld64(m, U32(a & ~3u) + lane4, lo, hi);
+	return funnel_shr(hi, lo, U32((a & 3u) << 3));
+}
 // 32 bits of the LDS bit stream (LSB first) from bit position bitpos on: the two aligned dwords around it, one funnel shift
 WV_FN U32 lds_ld32_bits(Lds m, const U32& bitpos)
 {
