@@ -351,6 +351,21 @@ WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const P
 	lds_put_bytes8(out, sel(anyw, rbase + ebits, dump), s1lo | pk[2], s1hi);
 }
 
+// The 16 v_perm_b32 selectors that move the bytes of a dword whose flag is 0 to its low end (entry f: flags f; lane f writes
+// it).  Once per run of blocks, into a place of its own.
+WV_FN void slot_write_rle_lut(Lds lds, const Layout& L)
+{
+	const U32 lane = lane_id();
+	U32 pat(0x0c0c0c0cu), at(0u);
+	for (uint32_t k = 0; k < 4; ++k) {
+		const Pred keep = ((lane >> k) & 1u) == U32(0u);
+		pat = sel(keep, (pat & ~(U32(0xFFu) << at)) | (U32(k) << at), pat);
+		at = at + sel(keep, U32(8u), U32(0u));
+	}
+	lds_st32(lds, U32(L.rlelut) + lane * 4u, pat, lane < U32(16u));
+	wave_sync();
+}
+
 // The rows of the slots into the zeroed image, once every slot knows where its plane starts (pbase, from the image's start):
 // header nibbles, minima, the mask of repeated minima, payloads (block_compress.h:739-806).  Shared by the three batch forms.
 WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, const Pred& valid, const U32& pbase)
@@ -384,34 +399,48 @@ WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, cons
 	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
+		// Few rows of a pass are run-length rows (one or two per block of smooth floats), but a loop over the row's four
+		// dwords by all 64 lanes costs the same for one such row as for 64.  So the rows are handed to quads of lanes: row
+		// number i of the pass (in lane order) goes to lanes 4i .. 4i+3, lane k takes the row's dword k -- flags, literals
+		// and where they go -- and one 8-byte OR per lane writes mask and literals.  The hand-over goes through the slot
+		// area (free by now: the rows are in registers), sixteen rows at a time.
 		const Pred is7 = hdr == U32(7u);
-		// table of the 16 v_perm_b32 selectors that move the bytes whose flag is 0 to the low end (lane f writes entry f;
-		// the row table of the plane-group path is not used here)
-		const uint32_t lut = L.rowinfo; // (free on this path; the slot area takes what idle lanes OR away, see put_small)
-		{
-			U32 pat(0x0c0c0c0cu), at(0u);
-			for (uint32_t k = 0; k < 4; ++k) {
-				const Pred keep = ((lane >> k) & 1u) == U32(0u);
-				pat = sel(keep, (pat & ~(U32(0xFFu) << at)) | (U32(k) << at), pat);
-				at = at + sel(keep, U32(8u), U32(0u));
-			}
-			lds_st32(lds, U32(lut) + lane * 4u, pat, lane < U32(16u));
+		const uint32_t lut = L.rlelut; // (slot_write_rle_lut, once per run)
+		const uint64_t rows = ballot(rle);
+		const uint32_t n = (uint32_t)__builtin_popcountll(rows);
+		const U32 rank = lane_rank(rows);
+		const uint32_t area = slot2_area(L); // entry i, 32 bytes: [payload offset][-][-][byte in front][the row's 16 bytes]
+		U128 d;
+		d.x = sel(is7, R.sb[0], R.sd[0]), d.y = sel(is7, R.sb[1], R.sd[1]), d.z = sel(is7, R.sb[2], R.sd[2]), d.w = sel(is7, R.sb[3], R.sd[3]);
+		// in front of a row of values: the last byte of the row above (:268-275); of a row of differences: no difference (:248-255)
+		const U32 front = sel(is7, row_shr(R.sb[3], 1, 0x80808080u), U32(0x80808080u));
+		const U32 k = lane & 3u, k4 = k << 2, quad = lane >> 2;
+		const U32 idle = U32(area - L.out + 512u) + (lane & 31u) * 16u; // where quads without a row OR what they have
+		for (uint32_t c = 0; c < n; c += 16) {
+			const U32 slotno = rank - U32(c);
+			const Pred mine = rle & (slotno < U32(16u));
+			const U32 ent = U32(area) + (slotno & 15u) * 32u;
+			lds_st32(lds, ent, rbase, mine);
+			lds_st32(lds, ent + 12u, front, mine);
+			lds_st128(lds, ent + 16u, d, mine);
+			wave_sync();
+			const U32 qe = U32(area) + quad * 32u;
+			U32 lo, hi;
+			lds_ld64(lds, qe + 12u + k4, lo, hi);
+			const U32 rb = lds_ld32(lds, qe);
+			// byte == byte in front of it
+			const U32 f = zero_mask_to_bits(bytes_zero_mask(hi ^ prev_bytes(hi, lo)));
+			const U32 lits = perm_bytes_v(U32(0u), hi ^ H, lds_ld32(lds, U32(lut) + f * 4u));
+			U32 f16 = f << k4;
+			f16 = f16 | shfl_xor(f16, 1);
+			f16 = f16 | shfl_xor(f16, 2);
+			const U32 before = popc(~f16 & ((U32(1u) << k4) - 1u)); // literals of the row in front of this lane's
+			const Pred first = k == U32(0u);
+			const U32 pos = rb + sel(first, U32(0u), before + 2u);
+			const Pred have = (U32(c) + quad) < U32(n);
+			lds_put_bytes8(out, sel(have, pos, idle), sel(first, f16 | (lits << 16), lits), sel(first, lits >> 16, U32(0u)));
 			wave_sync();
 		}
-		U32 f16(0u), lp = rbase + 2u;
-		for (int k = 0; k < 4; ++k) {
-			// byte == previous byte (:268-275) / delta == previous delta (:248-255)
-			const U32 bp = k ? prev_bytes(R.sb[k], R.sb[k - 1]) : prev_bytes(R.sb[0], row_shr(R.sb[3], 1, 0x80808080u));
-			const U32 dp = k ? prev_bytes(R.sd[k], R.sd[k - 1]) : ((R.sd[0] << 8) | 0x80u);
-			const U32 z = bytes_zero_mask(sel(is7, R.sb[k] ^ bp, R.sd[k] ^ dp));
-			const U32 f = zero_mask_to_bits(z);
-			f16 = f16 | (f << U32(4u * (uint32_t)k));
-			const U32 nlit = U32(4u) - popc(f);
-			const U32 lits = perm_bytes_v(U32(0u), sel(is7, R.sb[k], R.sd[k]) ^ H, lds_ld32(lds, U32(lut) + f * 4u));
-			put_bits(out, lp * 8u, lits, rle & (nlit != U32(0u)), own);
-			lp = lp + nlit;
-		}
-		put_bits(out, rbase * 8u, f16, rle, own);
 	}
 	WV_MARK("emit_end");
 	wave_sync();

@@ -217,6 +217,8 @@ struct NoPassHook {
 template <class Sink, class Hook = NoPassHook>
 WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, bool slots, Hook hook = Hook())
 {
+	if (slots && (T == 2 || T == 4 || T == 8))
+		slot_write_rle_lut(lds, L);
 	if (slots && (T == 2 || T == 4)) {
 		// Planes in slots (slot_codec.h): the non-constant planes of a block, and of its successor when they fit into
 		// the four slots together, are analysed and written by row lanes in one pass.

@@ -114,6 +114,13 @@ WV_FN U32 lane_id()
 	return r;
 }
 WV_FN U32 lane_id_plain() { return lane_id(); }
+// number of set bits of mask below the lane's own (v_mbcnt): the lane's rank among the lanes of the mask
+WV_FN U32 lane_rank(uint64_t mask)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = (uint32_t)__builtin_popcountll(mask & ((1ull << i) - 1ull));
+	return r;
+}
 WV_FN U32 umin(const U32& a, const U32& b)
 {
 	U32 r;
@@ -558,6 +565,8 @@ WV_FN U32 lane_id_plain()
 	__builtin_assume(l < 64u);
 	return l;
 }
+// number of set bits of mask below the lane's own: the lane's rank among the lanes of the mask
+WV_FN U32 lane_rank(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
 WV_FN U32 umin(U32 a, U32 b) { return a < b ? a : b; }
 WV_FN U32 umax(U32 a, U32 b) { return a > b ? a : b; }
 WV_FN U32 popc(U32 a) { return (U32)__builtin_popcount(a); }
