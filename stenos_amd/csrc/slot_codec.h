@@ -379,6 +379,16 @@ WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, cons
 	const U32 hdr = R.hdr();
 	const Pred israw = valid & (R.type() == U32(PLANE_RAW));
 	const Pred normal = valid & !israw;
+	if (!any(normal)) {
+		// Planes of noise only (the low bytes of doubles: four such planes fill the first pass of most blocks): their rows as they
+		// came (:1553-1565), sixteen bytes per lane -- no headers, no minima, nothing to pack.
+		const U32 to = pbase + r * 16u;
+		lds_put_bytes8(out, sel(valid, to, own), R.sb[0] ^ H, R.sb[1] ^ H);
+		lds_put_bytes8(out, sel(valid, to + 8u, own), R.sb[2] ^ H, R.sb[3] ^ H);
+		WV_MARK("emit_end_raw");
+		wave_sync();
+		return;
+	}
 	put_small(out, pbase * 8u + r * 4u, hdr, normal, own); // (:768-779, 758-762)
 	put_small(out, (pbase + (R.pm >> 16)) * 8u, R.minb() ^ 0x80u, normal & R.emitmin, own);
 	{
