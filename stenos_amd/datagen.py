@@ -52,7 +52,8 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     walk (x += u%17 - 8), dict16 (16-entry dictionary), runs (runs of 7), burst, ramp,
     sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal),
     mixed (per block and plane: constant / narrow / random / walk / runs), lzmix (per block: noise / dictionary /
-    half dictionary / constant, 12-bit values).
+    half dictionary / constant, 12-bit values), noise_low (noise below a slow ramp), steps (long runs of equal values),
+    slopes (piecewise linear).
     """
     if n == 0:
         return np.zeros(0, dtype=np.uint8)
@@ -124,6 +125,20 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
         if T == 4:
             return _as_bytes(x.astype("<f4"))
         raise ValueError("sine needs T in (4, 8)")
+    if kind == "noise_low":
+        # noise in the low half of the element, a slow ramp above it (the byte planes of doubles: whole passes of RAW planes)
+        h = max(1, T // 2)
+        a = generate("rand", T, n, seed + 13).reshape(n, T).copy()
+        a[:, h:] = _le_elements((np.arange(n, dtype=np.int64) // 3 + seed), T).reshape(n, T)[:, : T - h]
+        return a.reshape(-1)
+    if kind == "steps":
+        # long runs of equal values with jumps: most rows are run-length rows of values (row header 7)
+        v = (splitmix64(seed + 17, n // 9 + 2) & np.uint64(0x3FFFFFFF)).astype(np.int64)
+        return _le_elements(np.repeat(v, 9)[:n], T)
+    if kind == "slopes":
+        # piecewise linear: differences that repeat -- run-length rows of differences (row header 6)
+        d = (splitmix64(seed + 19, n // 11 + 2) % np.uint64(200)).astype(np.int64)
+        return _le_elements(np.cumsum(np.repeat(d, 11)[:n]), T)
     if kind == "smooth8":
         assert T == 1
         x = (128 + 100 * np.sin(0.01 * np.arange(n))).astype(np.int64) + (u % np.uint64(5)).astype(np.int64) - 2

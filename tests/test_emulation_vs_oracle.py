@@ -397,3 +397,45 @@ def test_fused_path_planes_of_noise(oracle, emul, T, dtype):
         r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), out.nbytes, 1)
         assert emul.emul_last_fused() > 0
         assert r1 == r2 and np.array_equal(ref, out[:r2]), trial
+
+
+@pytest.mark.parametrize("T", [2, 4, 8])
+def test_plane_forms_of_round_4(oracle, emul, T):
+    """The short plane forms of the decoder (block_codec.h decode_plane_packed: bit-packed rows, raw rows, run-length coded
+    differences; header-7 rows through the general form) and the encoder's run-length rows by quads (more than sixteen per
+    pass as well) and passes of noise (slot_codec.h), on inputs built to hold them -- the oracle's own counters say that they
+    do -- against the oracle, byte for byte, both ways; the decoder with and without its register path."""
+    from _libs import STAT_PLANE_TYPE, STAT_ROW_HDR, frame_stats, oracle_compress
+
+    emul.emul_run_compress.restype = c_size_t
+    emul.emul_run_compress.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p]
+    seen = np.zeros(16, dtype=np.uint64)
+    raw_planes = 0
+    for kind in ["sine", "walk", "noise_low", "steps", "slopes"]:
+        if kind == "sine" and T == 2:
+            continue
+        for n in (256 * 7, 256 * 64):
+            data = generate(kind, T, n, 5 + n)
+            nb = data.nbytes
+            r0, frame = oracle_compress(oracle, data, T, 1)
+            st = frame_stats(oracle, frame, T)
+            seen += st[STAT_ROW_HDR:STAT_ROW_HDR + 16]
+            raw_planes += int(st[STAT_PLANE_TYPE + 1])
+            if kind == "steps":  # (the gathered emission takes sixteen run-length rows at a time: a pass has to hold more)
+                assert st[STAT_ROW_HDR + 7] > (n // 256) * 20, st[STAT_ROW_HDR:STAT_ROW_HDR + 16]
+            if kind == "slopes":
+                assert st[STAT_ROW_HDR + 6] > (n // 256) * 8, st[STAT_ROW_HDR:STAT_ROW_HDR + 16]
+            ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+            out = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r2 = emul.emul_run_compress(np_ptr(data), T, n // 256, np_ptr(out))
+            assert r1 == r2 and np.array_equal(ref[:r1], out[:r1]), (kind, n)
+            for regs in (1, 0):
+                emul.emul_set_dec_regs(regs)
+                for mis in (0, 3):
+                    dec = np.zeros(nb + 64, dtype=np.uint8)
+                    r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), mis)
+                    assert r3 == nb and np.array_equal(dec[:nb], data), (kind, n, regs, mis)
+            emul.emul_set_dec_regs(1)
+    # every row kind has been through: absolute rows, rows of differences, both run-length kinds, raw rows; and RAW planes
+    assert seen[0:6].sum() > 0 and seen[8:15].sum() > 0 and seen[6] > 0 and seen[7] > 0 and seen[15] > 0 and raw_planes > 0, (seen, raw_planes)

@@ -112,6 +112,23 @@ def test_medium_sizes_against_oracle(lib, ctx, oracle, T, kind, n):
     assert r3 == data.nbytes and np.array_equal(back, data)
 
 
+@pytest.mark.parametrize("T", [2, 4, 8])
+@pytest.mark.parametrize("kind", ["sine", "walk", "noise_low", "steps", "slopes"])
+def test_plane_forms_of_round_4(lib, ctx, oracle, T, kind):
+    """The decoder's short plane forms and the encoder's run-length rows by quads and passes of noise on
+    inputs made of those row kinds (tests/test_emulation_vs_oracle.py asserts with the oracle's counters that they are), a few
+    MiB each so that every resident workgroup of the fused kernel gets superblocks."""
+    if kind == "sine" and T == 2:
+        pytest.skip("float data: bytesoftype 4 and 8")
+    n = (24 << 20) // T + 77
+    data = generate(kind, T, n, 31)
+    r1, ref = oracle_compress(oracle, data, T)
+    r2, out = gpu_compress(lib, ctx, data, T)
+    assert r1 == r2 and np.array_equal(ref, out)
+    r3, back = gpu_decompress(lib, ctx, ref, T, data.nbytes)
+    assert r3 == data.nbytes and np.array_equal(back, data)
+
+
 @pytest.mark.parametrize("T,kind,n", [(4, "rand", 300), (4, "walk", 5000), (2, "burst", 70001), (8, "dict16", 3000), (4, "rand12", 32768 + 200)])
 def test_shrinking_dst(lib, ctx, oracle, T, kind, n):
     """Compress must succeed when dst_size >= bound, may only fail with an error below it, and never
