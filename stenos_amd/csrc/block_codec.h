@@ -1133,7 +1133,7 @@ WV_FN void dec_write_lut(Lds lds, const DecLayout& L)
 // the lane begins is the literal in front of its own ones (none: 0), so the five bytes from there on and a table entry for
 // the lane's four flags (dec_write_lut: byte k = pool byte [number of clear flags up to k]) are one v_perm_b32.  No chain.
 // (Three copies -- plain, raw rows, raw and run-length rows: merged, the compiler turns the extras into selects that every plane pays.)
-template <bool has_raw, bool has_rle>
+template <bool has_raw, int has_rle> // has_rle: 0 no run-length rows, 1 of differences only (header 6), 2 of values too (header 7)
 WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t type, uint32_t cur, const U32& hdr, U32* keep)
 {
 	const U32 lane = lane_id_plain();
@@ -1141,7 +1141,7 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 	const U32 row = lane >> 2, q = lane & 3u;
 	U32 bits = hdr & 7u, m = hdr >> 3; // m = 1: a row of differences
 	U32 bytes = bits + bits;
-	U32 upto, minv, minat = row, nomin(~0u), rowoff, rmask(0u);
+	U32 upto, minv, minat = row, nomin(~0u), rowoff, rmask(0u), lead(0u);
 	uint32_t minslen = 16, rle_total = 0;
 	Pred isr = pred_all(false);
 	if (has_raw) {
@@ -1150,10 +1150,10 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		bits = bits + raw;
 		m = m ^ raw;
 		if (has_rle) {
-			isr = hdr == U32(6u);
+			isr = has_rle == 2 ? (hdr & 0xEu) == U32(6u) : hdr == U32(6u);
 			plain = sel(isr, U32(0u), plain);
 			bits = sel(isr, U32(0u), bits); // (no payload of known size: see below)
-			m = sel(isr, U32(1u), m);
+			m = sel(hdr == U32(6u), U32(1u), m);
 		}
 		nomin = U32(0u) - plain; // (no minimum is added to a raw row or a run-length row)
 		bytes = bits + bits;
@@ -1177,6 +1177,9 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 	rowoff = U32(cur + 8 + minslen) + (upto - bytes);
 	if (has_rle) {
 		WV_NESTED();
+		// (the same walk on scalars -- the payload read into registers once, two v_readlane_b32 and a 64-bit shift per row instead
+		// of two LDS reads -- was measured: +5 % on float32 sine, whose planes have one or two such rows, and no gain on frames
+		// made of run-length rows, whose time is the mini-LZ's)
 		uint64_t todo = ballot(isr) & 0x1111111111111111ull; // one bit per row: that of its first lane
 		U32 extra(0u);
 		while (todo) {
@@ -1206,11 +1209,32 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		px = sel(isr, perm_bytes_v(pool_hi, pool_lo, selw), px);
 		bits = sel(isr, U32(8u), bits);
 		bytes = bits + bits;
+		if (has_rle == 2) {
+			// A row of run-length coded VALUES (header 7, :285-293) repeats the value in front of an element whose flag is set: the
+			// literal in force, which the pool's first byte is -- or, in front of the row's first literal, the last value of the row
+			// above.  A lane all of whose elements do that hands its carry on like a lane of zero differences; in a lane that holds
+			// the row's first literal the elements in front of it take the carry (`lead`: their flags), the others are absolute.
+			const Pred nofront = (hdr == U32(7u)) & (before == U32(0u));
+			m = sel(nofront & (f == U32(0xFu)), U32(1u), m);
+			lead = sel(nofront, f, U32(0u));
+		}
 	}
 	const U32 v0 = bfe(px, U32(0u), bits) + minv, v1 = bfe(px, bits, bits) + minv, v2 = bfe(px, bytes, bits) + minv, v3 = bfe(px, bytes + bits, bits) + minv;
 	U32 o0 = v0, o1 = v1, o2 = v2, o3 = v3;
 	const uint64_t diff_rows = ballot(m != U32(0u));
-	if (diff_rows) {
+	if (has_rle == 2) {
+		// as below with the keys per lane (an absolute lane in front of the lane's own row may be the nearest one now), and the value
+		// behind the lane in front for every lane: lanes of differences add it to all their elements, the `lead` elements take it
+		o1 = mad24(m, o0, v1);
+		o2 = mad24(m, o1, v2);
+		o3 = mad24(m, o2, v3);
+		const U32 P = wave_incl_scan(mul24(m, o3));
+		const U32 K = wave_incl_scan_max(sel(m != U32(0u), U32(0u), ((lane + 1u) << 8) | ((o3 - P) & 0xFFu)));
+		const U32 cin = shfl_up(K + P, 1, 0);
+		const U32 l0 = lead & 1u, l1 = l0 & (lead >> 1), l2 = l1 & (lead >> 2), l3 = l2 & (lead >> 3);
+		o0 = mad24(m | l0, cin, o0), o1 = mad24(m | l1, cin, o1), o2 = mad24(m | l2, cin, o2), o3 = mad24(m | l3, cin, o3);
+	}
+	else if (diff_rows) {
 		// running sums inside the lane: difference lanes add up, absolute lanes keep their values (m = 0)
 		o1 = mad24(m, o0, v1);
 		o2 = mad24(m, o1, v2);
@@ -1234,7 +1258,9 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 	else
 		store_plane_word(lds, L.img, T, j, outw, pred_all(true));
 	// (no code: different last statements keep the compiler from folding the tails of the copies into one again)
-	if (has_rle)
+	if (has_rle == 2)
+		WV_MARK("dec_packed_rle7_end");
+	else if (has_rle)
 		WV_MARK("dec_packed_rle_end");
 	else if (has_raw)
 		WV_MARK("dec_packed_raw_end");
@@ -1264,12 +1290,14 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	U32 hdr, minv;
 	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
 #ifndef STENOS_DECODE_NO_PACKED_PATH
-	if (lines == 16 && ballot(hdr == U32(7u)) == 0) {
+	if (lines == 16) {
+		if (ballot(hdr == U32(7u)) != 0)
+			return decode_plane_packed<true, 2>(lds, L, T, j, type, cur, hdr, keep);
 		if (ballot(hdr == U32(6u)) != 0)
-			return decode_plane_packed<true, true>(lds, L, T, j, type, cur, hdr, keep);
+			return decode_plane_packed<true, 1>(lds, L, T, j, type, cur, hdr, keep);
 		if (ballot(hdr == U32(15u)) != 0)
-			return decode_plane_packed<true, false>(lds, L, T, j, type, cur, hdr, keep);
-		return decode_plane_packed<false, false>(lds, L, T, j, type, cur, hdr, keep);
+			return decode_plane_packed<true, 0>(lds, L, T, j, type, cur, hdr, keep);
+		return decode_plane_packed<false, 0>(lds, L, T, j, type, cur, hdr, keep);
 	}
 #endif
 	if (type == PLANE_NORMAL) {

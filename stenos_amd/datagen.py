@@ -170,7 +170,7 @@ def splitmix64_torch(seed: int, n: int, device, start: int = 0):
 
 def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25, start: int = 0):
     """Flat uint8 CUDA tensor holding elements [start, start + n) of the sequence `kind` (T bytes each);
-    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine, smooth8."""
+    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine, steps, smooth8."""
     import torch
 
     out = torch.empty(n * T, dtype=torch.uint8, device=device)
@@ -201,6 +201,12 @@ def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chu
         elif kind == "sine":
             x = torch.sin(torch.arange(s, s + m, dtype=torch.float64, device=device) * 0.001)
             v = x if T == 8 else x.to(torch.float32)
+        elif kind == "steps":  # (generate("steps"): element i = value number i // 9)
+            idx = torch.arange(s, s + m, dtype=torch.int64, device=device) // 9
+            z = (idx + 1) * (0x9E3779B97F4A7C15 - (1 << 64)) + (seed + 17)
+            z = (z ^ _lsr(z, 30)) * (0xBF58476D1CE4E5B9 - (1 << 64))
+            z = (z ^ _lsr(z, 27)) * (0x94D049BB133111EB - (1 << 64))
+            v = ((z ^ _lsr(z, 31)) & 0x3FFFFFFF).to({2: torch.int16, 4: torch.int32, 8: torch.int64}[T])
         elif kind == "smooth8":  # (the device's sin: the same signal as generate(), not bit for bit the same bytes)
             assert T == 1
             u = splitmix64_torch(seed, m, device, start=s)
