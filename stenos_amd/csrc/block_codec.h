@@ -1489,6 +1489,96 @@ WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, 
 	return p - cur;
 }
 
+// The same for 256 items (bytesoftype 4 and 8) in two phases instead of a chain of 32 groups with eight LDS round trips each.
+// Phase 1, the chain: where a group starts depends on the sizes of the items in front of it, and a match is one byte or two.
+// Taking every match for one byte makes a group's size a function of its flags byte alone: 32 dependent byte reads.
+// Phase 2, all items at once, four per lane: offsets from the flags, distances and literals read; the literals go to their
+// places in the image, and a table of 256 bytes says for every item where its value comes from -- itself (a literal) or the
+// item the match points at.  Pointer jumping on that table (a match's source may be a match: at most eight rounds, one byte
+// read and one byte written per item and round), then the values follow their pointers.  A match of two bytes (a distance
+// of 128 or more), a stream that ends early, a distance that points in front of the block: 0 is returned with nothing
+// decided, and lz_decode above does the block -- it also is what reports the errors.
+// The table lies behind the image, in the bytes the layout keeps readable there (make_dec_layout: 256 fit for both sizes).
+WV_FN uint32_t lz_decode_256(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail)
+{
+	const U32 lane = lane_id_plain();
+	Lds win = lds + L.win;
+	const uint32_t B = lz_width(T); // 4 or 8; 256 items, 32 groups
+	const uint32_t from = L.img + 256 * T; // from[i]: the item whose value item i takes
+	const uint32_t end = cur + avail;
+	uint32_t p = cur;
+	U32 rec(0u); // lane g: where group g starts | its flags << 16
+	for (uint32_t g = 0; g < 32; ++g) {
+		if (p + 2 > end)
+			return 0;
+		const uint32_t flags = win_u8(win, p);
+		rec = sel(lane == U32(g), U32(p | (flags << 16)), rec);
+		const uint32_t nm = (uint32_t)__builtin_popcount(flags);
+		p += 1 + nm + (8 - nm) * B;
+	}
+	if (p > end)
+		return 0;
+	const U32 mine = shfl(rec, lane >> 1); // the group of the lane's four items (items 4 * lane ...)
+	const U32 gp = mine & 0xFFFFu, gf = mine >> 16;
+	U32 ptr[4];
+	Pred match[4];
+	Pred bad = pred_all(false);
+	for (uint32_t k = 0; k < 4; ++k) {
+		const U32 j = ((lane & 1u) << 2) + k; // item of the group
+		const U32 idx = (lane << 2) + k;     // item of the block
+		const U32 mb = popc(gf & ((U32(1u) << j) - 1u)); // matches in front of it in the group
+		const U32 off = gp + 1u + mb + (j - mb) * B;
+		match[k] = ((gf >> j) & 1u) != U32(0u);
+		const U32 lo = lds_ld32_unaligned(win, off); // a literal, or a match's distance in its first byte
+		const U32 d = lo & 0xFFu;
+		bad = bad | (match[k] & ((d > U32(127u)) | (d == U32(0u)) | (d > idx)));
+		ptr[k] = sel(match[k], idx - d, idx);
+		lds_st32(lds, U32(L.img) + idx * B, lo, !match[k]);
+		if (B == 8)
+			lds_st32(lds, U32(L.img + 4) + idx * 8u, lds_ld32_unaligned(win, off + 4u), !match[k]);
+	}
+	if (any(bad))
+		return 0;
+	{
+		const U32 four = ptr[0] | (ptr[1] << 8) | (ptr[2] << 16) | (ptr[3] << 24); // (distances of matches never reach 256 items back here)
+		lds_st32(lds, U32(from) + (lane << 2), four, pred_all(true));
+	}
+	wave_sync();
+	// pointer jumping: an item that is its own source is a literal; a match takes over its source's source
+	for (uint32_t round = 0; round < 8; ++round) {
+		U32 next[4];
+		for (uint32_t k = 0; k < 4; ++k)
+			next[k] = lds_ld8(lds, U32(from) + ptr[k]);
+		wave_sync();
+		Pred moved = pred_all(false);
+		for (uint32_t k = 0; k < 4; ++k) {
+			moved = moved | (next[k] != ptr[k]);
+			ptr[k] = next[k];
+		}
+		const U32 four = ptr[0] | (ptr[1] << 8) | (ptr[2] << 16) | (ptr[3] << 24);
+		lds_st32(lds, U32(from) + (lane << 2), four, pred_all(true));
+		wave_sync();
+		if (!any(moved))
+			break;
+	}
+	// (after eight rounds every chain of at most 255 links has ended at a literal)
+	U32 vlo[4], vhi[4];
+	for (uint32_t k = 0; k < 4; ++k) {
+		const U32 a = U32(L.img) + ptr[k] * B;
+		vlo[k] = lds_ld32(lds, a);
+		vhi[k] = B == 8 ? lds_ld32(lds, a + 4u) : U32(0u);
+	}
+	wave_sync();
+	for (uint32_t k = 0; k < 4; ++k) {
+		const U32 a = U32(L.img) + ((lane << 2) + k) * B;
+		lds_st32(lds, a, vlo[k], match[k]);
+		if (B == 8)
+			lds_st32(lds, a + 4u, vhi[k], match[k]);
+	}
+	wave_sync();
+	return p - cur;
+}
+
 // A full block of bytesoftype 2, 4 or 8 made of planes (not COPY, not LZ), straight to HBM: the lane's word of every plane
 // stays in a register, three (bytesoftype 2: one) v_perm_b32 per element turn them into the lane's four elements and one
 // or two 16-byte stores write them.  No byte stores into an element-major image (stride 4*T between the lanes: LDS bank
@@ -1591,7 +1681,13 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 		if (first == BLOCK_LZ) { // (:1829-1835)
 			if (T % 4 != 0)
 				return DEC_ERROR;
-			uint32_t n = lz_decode(lds, L, T, cur + 1, avail - 1);
+			uint32_t n = 0;
+#ifndef STENOS_LZ_DECODE_SERIAL
+			if (T == 4 || T == 8)
+				n = lz_decode_256(lds, L, T, cur + 1, avail - 1);
+#endif
+			if (n == 0)
+				n = lz_decode(lds, L, T, cur + 1, avail - 1);
 			if (n == DEC_ERROR)
 				return DEC_ERROR;
 			if (direct) {

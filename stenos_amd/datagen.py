@@ -53,7 +53,7 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal),
     mixed (per block and plane: constant / narrow / random / walk / runs), lzmix (per block: noise / dictionary /
     half dictionary / constant, 12-bit values), noise_low (noise below a slow ramp), steps (long runs of equal values),
-    slopes (piecewise linear).
+    slopes (piecewise linear), cycle130 (a cycle of 130 values).
     """
     if n == 0:
         return np.zeros(0, dtype=np.uint8)
@@ -139,6 +139,10 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
         # piecewise linear: differences that repeat -- run-length rows of differences (row header 6)
         d = (splitmix64(seed + 19, n // 11 + 2) % np.uint64(200)).astype(np.int64)
         return _le_elements(np.cumsum(np.repeat(d, 11)[:n]), T)
+    if kind == "cycle130":
+        # 130 distinct values over and over: the mini-LZ finds every value 130 items back (distances of two bytes)
+        v = (splitmix64(seed + 23, 130) >> np.uint64(2)).astype(np.int64)  # (noise in every byte: the attempt is not turned away early)
+        return _le_elements(np.tile(v, n // 130 + 1)[:n], T)
     if kind == "smooth8":
         assert T == 1
         x = (128 + 100 * np.sin(0.01 * np.arange(n))).astype(np.int64) + (u % np.uint64(5)).astype(np.int64) - 2
@@ -170,7 +174,7 @@ def splitmix64_torch(seed: int, n: int, device, start: int = 0):
 
 def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chunk: int = 1 << 25, start: int = 0):
     """Flat uint8 CUDA tensor holding elements [start, start + n) of the sequence `kind` (T bytes each);
-    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine, steps, smooth8."""
+    kinds: sorted_i32, rand, rand12, rand8, walk (start must be 0), sine, dict16, steps, smooth8."""
     import torch
 
     out = torch.empty(n * T, dtype=torch.uint8, device=device)
@@ -201,6 +205,9 @@ def generate_torch(kind: str, T: int, n: int, seed: int = 42, device="cuda", chu
         elif kind == "sine":
             x = torch.sin(torch.arange(s, s + m, dtype=torch.float64, device=device) * 0.001)
             v = x if T == 8 else x.to(torch.float32)
+        elif kind == "dict16":
+            d = torch.from_numpy(generate("rand", T, 16, seed + 1).reshape(16, T)).to(device)
+            v = d[(splitmix64_torch(seed, m, device, start=s) & 15)]
         elif kind == "steps":  # (generate("steps"): element i = value number i // 9)
             idx = torch.arange(s, s + m, dtype=torch.int64, device=device) // 9
             z = (idx + 1) * (0x9E3779B97F4A7C15 - (1 << 64)) + (seed + 17)

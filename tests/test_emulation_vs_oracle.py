@@ -439,3 +439,35 @@ def test_plane_forms_of_round_4(oracle, emul, T):
             emul.emul_set_dec_regs(1)
     # every row kind has been through: absolute rows, rows of differences, both run-length kinds, raw rows; and RAW planes
     assert seen[0:6].sum() > 0 and seen[8:15].sum() > 0 and seen[6] > 0 and seen[7] > 0 and seen[15] > 0 and raw_planes > 0, (seen, raw_planes)
+
+
+@pytest.mark.parametrize("T", [4, 8])
+def test_mini_lz_blocks_both_decoders(oracle, emul, T):
+    """Blocks the mini-LZ took (block_codec.h): the two-phase decoder for 256 items (matches of one byte: small
+    dictionaries) and the chain of groups it falls back to (a cycle of 130 values: distances of two bytes), on frames that are made
+    of such blocks -- the oracle's counter says so."""
+    from _libs import STAT_LZ, frame_stats, oracle_compress
+
+    for kind in ["dict16", "lzmix", "cycle130"]:
+        lz_blocks = 0
+        for n in (256 * 5, 256 * 40 + 77):
+            data = generate(kind, T, n, 9 + n)
+            nb = data.nbytes
+            r0, frame = oracle_compress(oracle, data, T, 1)
+            st = frame_stats(oracle, frame, T)
+            lz_blocks += int(st[STAT_LZ])
+            ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+            for regs in (1, 0):
+                emul.emul_set_dec_regs(regs)
+                for mis in (0, 5):
+                    dec = np.zeros(nb + 64, dtype=np.uint8)
+                    r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), mis)
+                    assert r3 == nb and np.array_equal(dec[:nb], data), (kind, n, regs, mis)
+            emul.emul_set_dec_regs(1)
+            # cut short and damaged streams: an error or the oracle's answer, never a crash
+            for cut in (r1 - 1, r1 // 2, 40):
+                dec = np.zeros(nb + 64, dtype=np.uint8)
+                r4 = emul.emul_block_decompress(np_ptr(ref), cut, T, nb, np_ptr(dec), 0)
+                assert has_error(r4) or r4 == nb, (kind, n, cut)
+        assert lz_blocks >= 5 or (kind == "lzmix" and T == 8), (kind, lz_blocks)  # (12-bit values in 8 bytes: too few planes for an attempt)

@@ -113,11 +113,12 @@ def test_medium_sizes_against_oracle(lib, ctx, oracle, T, kind, n):
 
 
 @pytest.mark.parametrize("T", [2, 4, 8])
-@pytest.mark.parametrize("kind", ["sine", "walk", "noise_low", "steps", "slopes"])
+@pytest.mark.parametrize("kind", ["sine", "walk", "noise_low", "steps", "slopes", "dict16", "cycle130"])
 def test_plane_forms_of_round_4(lib, ctx, oracle, T, kind):
     """The decoder's short plane forms and the encoder's run-length rows by quads and passes of noise on
     inputs made of those row kinds (tests/test_emulation_vs_oracle.py asserts with the oracle's counters that they are), a few
-    MiB each so that every resident workgroup of the fused kernel gets superblocks."""
+    MiB each so that every resident workgroup of the fused kernel gets superblocks; and blocks the mini-LZ took, for both of its
+    decoders (dict16: matches of one byte, the two-phase form; cycle130: two bytes, the chain of groups)."""
     if kind == "sine" and T == 2:
         pytest.skip("float data: bytesoftype 4 and 8")
     n = (24 << 20) // T + 77
