@@ -1291,12 +1291,17 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	hdr = (lds_ld8(win, U32(cur) + (row >> 1)) >> ((row & 1u) << 2)) & 0xFu;
 #ifndef STENOS_DECODE_NO_PACKED_PATH
 	if (lines == 16) {
-		if (ballot(hdr == U32(7u)) != 0)
-			return decode_plane_packed<true, 2>(lds, L, T, j, type, cur, hdr, keep);
-		if (ballot(hdr == U32(6u)) != 0)
-			return decode_plane_packed<true, 1>(lds, L, T, j, type, cur, hdr, keep);
-		if (ballot(hdr == U32(15u)) != 0)
+		// which copy: two bits per header out of a constant (0 plain, 1 raw, 2 and 3 the run-length kinds) -- two cheap
+		// instructions and one compare for the usual plane instead of three compares
+		const U32 kind = (U32(0x4000E000u) >> (hdr + hdr)) & 3u;
+		if (ballot(kind != U32(0u)) != 0) {
+			WV_NESTED();
+			if (ballot(kind == U32(3u)) != 0)
+				return decode_plane_packed<true, 2>(lds, L, T, j, type, cur, hdr, keep);
+			if (ballot(kind == U32(2u)) != 0)
+				return decode_plane_packed<true, 1>(lds, L, T, j, type, cur, hdr, keep);
 			return decode_plane_packed<true, 0>(lds, L, T, j, type, cur, hdr, keep);
+		}
 		return decode_plane_packed<false, 0>(lds, L, T, j, type, cur, hdr, keep);
 	}
 #endif
