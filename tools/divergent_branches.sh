@@ -18,3 +18,4 @@ for k in "${keys[@]}"; do
   echo "== $k"
   python3 "$here/tools/divergent_branches.py" "$here/build/uniformity.ll" "$here/build/uniformity.txt" "$k" | sort | uniq -c | sort -rn
 done
+rm -f "$here/build/uniformity.ll" "$here/build/uniformity.txt"  # (build/ travels to the GPU box: no listings left behind)
