@@ -887,6 +887,36 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 			H = sel(s, lds_ld32(lds, U32(chain) + sel(s, H, U32(0u)) * 4u), H);
 		}
 
+		// All eight groups of the chunk at once where none of them can be left raw (a group is, when the count of groups without
+		// a match has reached its limit: then the candidates of the lanes behind it change, and the groups go one by one below):
+		// the usual case for data the mini-LZ is made for, where every group finds matches.
+		{
+			const Pred cand = H != U32(LZ_NONE);
+			const LzVal hv = lz_value(lds, L.in, B, sel(cand, H, U32(0u)));
+			const Pred m = cand & (hv.lo == v.lo) & (hv.hi == v.hi);
+			const uint64_t mb = ballot(m), fb = ballot(m & ((pos - H) >= U32(128u)));
+			uint32_t empty = 0;
+			for (uint32_t k = 0; k < 8; ++k)
+				empty += ((mb >> (8 * k)) & 0xFFu) == 0;
+			if (failed + empty < max_failed) {
+				bool over = false;
+				for (uint32_t k = 0; k < 8; ++k) {
+					const uint32_t nm = (uint32_t)__builtin_popcountll((mb >> (8 * k)) & 0xFFu), nf = (uint32_t)__builtin_popcountll((fb >> (8 * k)) & 0xFFu);
+					failed += (nm == 0);
+					produced += 1 + 8 * B - nm * (B - 1) + nf;
+					over |= produced > max_size; // (:221-223)
+					if (!once && (c * 8 + k) * 8 > quarter) { // (:224-229)
+						over |= 5 * produced > 2 * max_size;
+						once = true;
+					}
+				}
+				if (over)
+					return 0;
+				lds_st32(lds, U32(cur) + pos * 4u, H, pred_all(true));
+				wave_sync();
+				continue;
+			}
+		}
 		// the 8 groups of this chunk, in order
 		for (uint32_t k = 0; k < 8; ++k) {
 			const uint32_t g = c * 8 + k;
