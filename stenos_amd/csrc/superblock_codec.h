@@ -386,12 +386,12 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					if (B.full[0] * 3 > bs && lz_precheck_passes(T, keys0, B.full[0])) {
 						const RawBlock e = load_raw_block(a, T);
 						if (!lz_repeats_reject(lds, M, e.e, B.full[0]) && lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[0]))
-							lzq |= 1u;
+							lzq |= 1u, lds_st32(lds, U32(M.plinfo), U32(B.full[0]), lane_id() == U32(0u));
 					}
 					if (nblk > 1 && B.full[1] * 3 > bs && lz_precheck_passes(T, keys1, B.full[1])) {
 						const RawBlock e = load_raw_block(b, T);
 						if (!lz_repeats_reject(lds, M, e.e, B.full[1]) && lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, e.e), B.full[1]))
-							lzq |= 2u;
+							lzq |= 2u, lds_st32(lds, U32(M.plinfo + 4), U32(B.full[1]), lane_id() == U32(0u));
 					}
 				}
 				if (!lzq) {
@@ -412,13 +412,22 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					return;
 				}
 			}
-			// a mini-LZ attempt: the general block encoder, one block at a time
-			// (the raw bytes of a measured superblock have been put in place already, above)
+			// a mini-LZ attempt, one block at a time (the raw bytes of a measured superblock have been put in place already,
+			// above).  The candidates' sizes without the mini-LZ are known from the pass -- it left them in the plane table's
+			// place, so that nothing of this rare path is alive in the pass --: the attempt needs nothing else, and the general
+			// encoder only runs for a block whose attempt fails or that was not a candidate.
+			wave_sync();
+			const uint32_t lzfull0 = readlane(lds_ld32(lds, U32(L.plinfo)), 0), lzfull1 = readlane(lds_ld32(lds, U32(L.plinfo + 4)), 0);
 			for (uint32_t q = 0; q < nblk; ++q) {
 				load_block(lds, L.in, q ? b : a, bs);
 				wave_sync();
 				const Layout M = sink.at(L);
-				const BlockInfo r = encode_full_block(lds, M, T, true, sink.base());
+				const uint32_t n = ((lzq >> q) & 1u) ? lz_try(lds, M, T, q ? lzfull1 : lzfull0, sink.base()) : 0u;
+				if (n) {
+					sink.append(lds, M, n + 1);
+					continue;
+				}
+				const BlockInfo r = encode_full_block(lds, M, T, false, sink.base());
 				sink.append(lds, M, r.size);
 			}
 			i += nblk;
@@ -474,7 +483,12 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			if (full * 3 > bs && lz_precheck_passes(8, keys, full) && !lz_repeats_reject8(lds, M, eb, full)) { // a mini-LZ attempt: the general block encoder
 				load_block(lds, L.in, a, bs);
 				wave_sync();
-				const BlockInfo r = encode_full_block(lds, M, 8, true, sink.base());
+				const uint32_t n = lz_try(lds, M, 8, full, sink.base()); // (its size without the mini-LZ is known: nothing else is needed)
+				if (n) {
+					sink.append(lds, M, n + 1);
+					continue;
+				}
+				const BlockInfo r = encode_full_block(lds, M, 8, false, sink.base());
 				sink.append(lds, M, r.size);
 				continue;
 			}
