@@ -1526,13 +1526,14 @@ WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, 
 
 // The same for 256 items (bytesoftype 4 and 8) in two phases instead of a chain of 32 groups with eight LDS round trips each.
 // Phase 1, the chain: where a group starts depends on the sizes of the items in front of it, and a match is one byte or two.
-// Taking every match for one byte makes a group's size a function of its flags byte alone: 32 dependent byte reads.
+// Taking every match for one byte makes a group's size a function of its flags byte alone: 32 dependent byte reads; if a match
+// of two bytes shows up (a distance of 128 or more), the chain is walked again with the groups sized exactly.
 // Phase 2, all items at once, four per lane: offsets from the flags, distances and literals read; the literals go to their
 // places in the image, and a table of 256 bytes says for every item where its value comes from -- itself (a literal) or the
 // item the match points at.  Pointer jumping on that table (a match's source may be a match: at most eight rounds, one byte
-// read and one byte written per item and round), then the values follow their pointers.  A match of two bytes (a distance
-// of 128 or more), a stream that ends early, a distance that points in front of the block: 0 is returned with nothing
-// decided, and lz_decode above does the block -- it also is what reports the errors.
+// read and one byte written per item and round), then the values follow their pointers.  A stream that ends early, a
+// distance that points in front of the block: 0 is returned with nothing decided, and lz_decode above does the block -- it
+// is what reports the errors.
 // The table lies behind the image, in the bytes the layout keeps readable there (make_dec_layout: 256 fit for both sizes).
 WV_FN uint32_t lz_decode_256(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail)
 {
@@ -1541,39 +1542,72 @@ WV_FN uint32_t lz_decode_256(Lds lds, const DecLayout& L, uint32_t T, uint32_t c
 	const uint32_t B = lz_width(T); // 4 or 8; 256 items, 32 groups
 	const uint32_t from = L.img + 256 * T; // from[i]: the item whose value item i takes
 	const uint32_t end = cur + avail;
-	uint32_t p = cur;
-	U32 rec(0u); // lane g: where group g starts | its flags << 16
-	for (uint32_t g = 0; g < 32; ++g) {
-		if (p + 2 > end)
-			return 0;
-		const uint32_t flags = win_u8(win, p);
-		rec = sel(lane == U32(g), U32(p | (flags << 16)), rec);
-		const uint32_t nm = (uint32_t)__builtin_popcount(flags);
-		p += 1 + nm + (8 - nm) * B;
-	}
-	if (p > end)
-		return 0;
-	const U32 mine = shfl(rec, lane >> 1); // the group of the lane's four items (items 4 * lane ...)
-	const U32 gp = mine & 0xFFFFu, gf = mine >> 16;
 	U32 ptr[4];
 	Pred match[4];
-	Pred bad = pred_all(false);
-	for (uint32_t k = 0; k < 4; ++k) {
-		const U32 j = ((lane & 1u) << 2) + k; // item of the group
-		const U32 idx = (lane << 2) + k;     // item of the block
-		const U32 mb = popc(gf & ((U32(1u) << j) - 1u)); // matches in front of it in the group
-		const U32 off = gp + 1u + mb + (j - mb) * B;
-		match[k] = ((gf >> j) & 1u) != U32(0u);
-		const U32 lo = lds_ld32_unaligned(win, off); // a literal, or a match's distance in its first byte
-		const U32 d = lo & 0xFFu;
-		bad = bad | (match[k] & ((d > U32(127u)) | (d == U32(0u)) | (d > idx)));
-		ptr[k] = sel(match[k], idx - d, idx);
-		lds_st32(lds, U32(L.img) + idx * B, lo, !match[k]);
-		if (B == 8)
-			lds_st32(lds, U32(L.img + 4) + idx * 8u, lds_ld32_unaligned(win, off + 4u), !match[k]);
+	uint32_t p = cur;
+	// First with every match taken for one byte; if one turns out to have two, once more with the groups sized exactly.
+	for (uint32_t exact = 0;; ++exact) {
+		p = cur;
+		U32 rec(0u); // lane g: where group g starts | its flags << 16 | which of its matches have two bytes << 24
+		for (uint32_t g = 0; g < 32; ++g) {
+			if (p + 2 > end)
+				return 0;
+			const uint32_t flags = win_u8(win, p);
+			uint32_t two = 0, len;
+			if (exact) {
+				// the group's bytes behind the flags, one per lane (an item starts at most 56 bytes in): a match has two bytes when
+				// its first one has bit 7 set -- eight steps on scalars, one v_readlane_b32 each
+				const U32 bytes = lds_ld8(win, U32(p + 1) + lane);
+				uint32_t at = 0;
+				for (uint32_t j = 0; j < 8; ++j) {
+					if ((flags >> j) & 1u) {
+						const uint32_t t = readlane(bytes, at) >> 7;
+						two |= t << j;
+						at += 1 + t;
+					}
+					else
+						at += B;
+				}
+				len = 1 + at;
+			}
+			else {
+				const uint32_t nm = (uint32_t)__builtin_popcount(flags);
+				len = 1 + nm + (8 - nm) * B;
+			}
+			rec = sel(lane == U32(g), U32(p | (flags << 16) | (two << 24)), rec);
+			p += len;
+		}
+		if (p > end)
+			return 0;
+		const U32 mine = shfl(rec, lane >> 1); // the group of the lane's four items (items 4 * lane ...)
+		const U32 gp = mine & 0xFFFFu, gf = (mine >> 16) & 0xFFu, gt = mine >> 24;
+		Pred bad = pred_all(false), longer = pred_all(false);
+		for (uint32_t k = 0; k < 4; ++k) {
+			const U32 j = ((lane & 1u) << 2) + k; // item of the group
+			const U32 idx = (lane << 2) + k;     // item of the block
+			const U32 below = (U32(1u) << j) - 1u;
+			const U32 mb = popc(gf & below); // matches in front of it in the group
+			const U32 off = gp + 1u + mb + popc(gt & below) + (j - mb) * B;
+			match[k] = ((gf >> j) & 1u) != U32(0u);
+			const Pred two = ((gt >> j) & 1u) != U32(0u);
+			const U32 lo = lds_ld32_unaligned(win, off); // a literal, or a match's distance in its first byte or two
+			const U32 d = sel(two, (lo & 127u) | ((lo >> 1) & 0x7F80u), lo & 0xFFu);
+			longer = longer | (match[k] & !two & ((lo & 0x80u) != U32(0u)));
+			bad = bad | (match[k] & ((d == U32(0u)) | (d > idx)));
+			ptr[k] = sel(match[k], idx - d, idx);
+			lds_st32(lds, U32(L.img) + idx * B, lo, !match[k]);
+			if (B == 8)
+				lds_st32(lds, U32(L.img + 4) + idx * 8u, lds_ld32_unaligned(win, off + 4u), !match[k]);
+		}
+		if (any(longer)) {
+			if (exact)
+				return 0;
+			continue;
+		}
+		if (any(bad))
+			return 0;
+		break;
 	}
-	if (any(bad))
-		return 0;
 	{
 		const U32 four = ptr[0] | (ptr[1] << 8) | (ptr[2] << 16) | (ptr[3] << 24); // (distances of matches never reach 256 items back here)
 		lds_st32(lds, U32(from) + (lane << 2), four, pred_all(true));
