@@ -6,8 +6,9 @@ region and per class (vector cheap / vector other / scalar / nop / wait / branch
 decisions run out, the tool prints the branch it stopped at with some context, so that a path can be worked out
 interactively with the source next to it.
 usage: isa_path.py build/enc4.s <start line> <stop regex> <decisions> [-v]
-Decision strings worked out in round 3 (they hold while the branch structure of the kernel does; the start line is the
-line of the named mark inside the kernel):
+Decision strings worked out in rounds 3 and 4 (they hold while the branch structure of the kernel does -- the last cuts of
+round 4 (run-length rows by quads, passes of noise, the mini-LZ's direct attempt, the decoders' plane forms) came after them, so
+they have to be worked out again before they are quoted; the start line is the line of the named mark inside the kernel):
   tools/isa_path_rand12.decisions         encode_superblocks<4>, kernels.hip built as in csrc/Makefile: one pass of two int32
                                           blocks u & 0xFFF, from MARK load_block to MARK block_end (486 vector + 244 scalar)
   tools/isa_path_decode_rand12.decisions  decode_superblocks<4>, decode_kernels.hip built as in csrc/Makefile: one such
