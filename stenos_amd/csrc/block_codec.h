@@ -1211,16 +1211,20 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		// of two LDS reads -- was measured: +5 % on float32 sine, whose planes have one or two such rows, and no gain on frames
 		// made of run-length rows, whose time is the mini-LZ's)
 		uint64_t todo = ballot(isr) & 0x1111111111111111ull; // one bit per row: that of its first lane
-		U32 extra(0u);
+		U32 extra(0u), total(0u);
 		while (todo) {
 			const uint32_t rl = (uint32_t)__builtin_ctzll(todo);
 			todo &= todo - 1;
-			const uint32_t mk = win_u16(win, readlane(rowoff + extra, rl));
-			const uint32_t sz = 2 + 16 - (uint32_t)__builtin_popcount(mk);
-			rmask = sel(row == U32(rl >> 2), U32(mk), rmask);
-			extra = extra + sel(row > U32(rl >> 2), U32(sz), U32(0u));
-			rle_total += sz;
+			// (the mask and the size stay in vector registers, the same in all lanes: the step's chain does not pass through the
+			// scalar unit behind the one lane read that makes the address)
+			const U32 at(readlane(rowoff + extra, rl));
+			const U32 mk = lds_ld8(win, at) | (lds_ld8(win, at + 1u) << 8);
+			const U32 sz = U32(18u) - popc(mk);
+			rmask = sel(row == U32(rl >> 2), mk, rmask);
+			extra = extra + sel(row > U32(rl >> 2), sz, U32(0u));
+			total = total + sz;
 		}
+		rle_total = readlane(total, 0);
 		rowoff = rowoff + extra;
 	}
 	const uint32_t psize = 8 + minslen + (readlane(upto, 63) & 0xFFFFu) + rle_total;
