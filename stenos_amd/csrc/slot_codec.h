@@ -149,28 +149,37 @@ WV_FN U32 biased_sub(const U32& a, const U32& p)
 // (hi << 8) | (lo >> 24): the dword that starts one byte before hi
 WV_FN U32 prev_bytes(const U32& hi, const U32& lo) { return (hi << 8) | (lo >> 24); }
 
-// number of non-zero bytes among the 16 bytes x[0..3]: bit 7 of every byte says "not zero", and a dot product with ones adds
-// the sixteen flags up (four v_dot4_u32_u8 instead of merging the flags of the four dwords into one for a population count)
+// number of non-zero bytes among the 16 bytes x[0..3]: v_msad_u8 adds |a - ref| over the bytes whose ref is not zero, and
+// a = ref ^ 1 differs from ref by exactly one in every byte -- two instructions per dword (the flags-and-dot-product form
+// took four)
 WV_FN U32 count_nonzero16(const U32* x)
 {
-	const U32 M(0x7f7f7f7fu);
 	U32 acc(0u);
 	for (int k = 0; k < 4; ++k)
-		acc = dot4_u8((((x[k] & M) + M) | x[k]) & 0x80808080u, 0x01010101u, acc);
-	return acc >> 7;
+		acc = msad_u8(x[k] ^ 0x01010101u, x[k], acc);
+	return acc;
 }
-// smallest and largest of the 16 bytes s[0..3] (unsigned).  A 16-bit minimum has the smallest high byte, so odd bytes are
-// compared where they are and even bytes after a shift by 8 (whatever follows them in the low byte does not matter).
-WV_FN void range16(const U32* s, U32& mn, U32& mx)
+// Smallest and largest of the 16 bytes s[0..3] (unsigned), in two halves.  A 16-bit minimum has the smallest high byte, so
+// the odd bytes are compared where they are (range_odd: both results still packed, [upper half | lower half] of 16-bit
+// values whose high bytes count) and the even bytes after a shift by 8 (whatever follows them in the low byte does not matter).
+WV_FN void range_odd(const U32* s, U32& lo, U32& hi)
+{
+	lo = pk_min_u16(pk_min_u16(s[0], s[1]), pk_min_u16(s[2], s[3]));
+	hi = pk_max_u16(pk_max_u16(s[0], s[1]), pk_max_u16(s[2], s[3]));
+}
+WV_FN void range16(const U32* s, const U32& lo_odd, const U32& hi_odd, U32& mn, U32& mx)
 {
 	U32 e[4];
 	for (int k = 0; k < 4; ++k)
 		e[k] = s[k] << 8;
-	const U32 lo = pk_min_u16(pk_min_u16(pk_min_u16(s[0], s[1]), pk_min_u16(s[2], s[3])), pk_min_u16(pk_min_u16(e[0], e[1]), pk_min_u16(e[2], e[3])));
-	const U32 hi = pk_max_u16(pk_max_u16(pk_max_u16(s[0], s[1]), pk_max_u16(s[2], s[3])), pk_max_u16(pk_max_u16(e[0], e[1]), pk_max_u16(e[2], e[3])));
+	const U32 lo = pk_min_u16(lo_odd, pk_min_u16(pk_min_u16(e[0], e[1]), pk_min_u16(e[2], e[3])));
+	const U32 hi = pk_max_u16(hi_odd, pk_max_u16(pk_max_u16(e[0], e[1]), pk_max_u16(e[2], e[3])));
 	mn = umin(lo >> 16, lo & 0xFFFFu) >> 8;
 	mx = umax(hi >> 16, hi & 0xFFFFu) >> 8;
 }
+// the packed results of range_odd span at least 0x4100 as 16-bit values: the largest and the smallest of the bytes they were
+// taken from -- and so of the whole row -- are at least 64 apart
+WV_FN Pred odd_range_is_wide(const U32& lo, const U32& hi) { return umax(hi >> 16, hi & 0xFFFFu) - umin(lo >> 16, lo & 0xFFFFu) >= U32(0x4100u); }
 // bits needed for v in 0..255 (0 for 0)
 WV_FN U32 bitlen8(const U32& v) { return bitlen((v << 1) | 1u) - 1u; }
 
@@ -192,13 +201,23 @@ struct SlotRows {
 };
 
 // Analyse the four slots as full-block planes (rle enabled, raw above 256 bytes: block_compress.h:1110-1111, 1190, 1200-1204).
-WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
+// slot_off: byte offset of the pass's four slots inside the slot area (a multiple of 1024; passes of a group of blocks keep
+// their slots side by side).  nvalid: slots in use (the lanes of the others hold stale bytes).
+//
+// Planes of noise are proven RAW before the row decisions are taken.  A row whose bytes span at least 64 and whose
+// differences span at least 64 needs 8 bits either way (:336-339, 422): 16 bytes and header 15, unless a run-length form is
+// strictly shorter (:464-472), which takes three repeated values or three repeated differences in the row.  When no row of a
+// plane gets below 16 bytes, no row writes a minimum (:480-490) and the plane measures 8 + 256 > 256: RAW (:1200-1204).  The
+// spans are taken over the odd bytes only -- half of the range computation, which the full analysis continues from when
+// some plane of the pass is not noise -- and that is enough: eight random bytes span less than 64 once in two thousand rows.
+// Returns true when every slot in use was proven RAW: R then holds the rows' bytes, size and type, and nothing else.
+WV_FN bool slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R, uint32_t slot_off = 0, uint32_t nvalid = 4, bool try_raw = true)
 {
 	const U32 lane = lane_id();
 	const U32 H(0x80808080u);
 	WV_MARK("analyse_stage1");
 	{
-		const U128 v = lds_ld128(lds, U32(slot2_area(L)) + lane * 16u);
+		const U128 v = lds_ld128(lds, U32(slot2_area(L) + slot_off) + lane * 16u);
 		R.sb[0] = v.x ^ H;
 		R.sb[1] = v.y ^ H;
 		R.sb[2] = v.z ^ H;
@@ -223,9 +242,22 @@ WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
 	for (int k = 1; k < 4; ++k)
 		x[k] = R.sd[k] ^ prev_bytes(R.sd[k], R.sd[k - 1]);
 	const U32 c2 = count_nonzero16(x) + 2u; // (:470-472)
+	U32 lo, hi, dlo, dhi;
+	range_odd(R.sb, lo, hi);
+	range_odd(R.sd, dlo, dhi);
+	if (try_raw) {
+		const Pred noise = odd_range_is_wide(lo, hi) & odd_range_is_wide(dlo, dhi) & (umin(c1, c2) >= U32(16u));
+		if (ballot(noise | (lane >= U32(16u * nvalid))) == ~0ull) {
+			R.ts = U32(256u | (PLANE_RAW << 16));
+			R.hm = R.pm = U32(0u);
+			R.emitmin = R.eq = pred_all(false);
+			WV_MARK("analyse_raw");
+			return true;
+		}
+	}
 	U32 mn, mx, dmn, dmx;
-	range16(R.sb, mn, mx);
-	range16(R.sd, dmn, dmx);
+	range16(R.sb, lo, hi, mn, mx);
+	range16(R.sd, dlo, dhi, dmn, dmx);
 
 	WV_MARK("analyse_stage2");
 	U32 b0 = bitlen8(mx - mn), b1 = bitlen8(dmx - dmn);
@@ -258,6 +290,7 @@ WV_FN void slot_rows_analyse(Lds lds, const Layout& L, SlotRows& R)
 	R.emitmin = (minsrle & !R.eq) | (!minsrle & !nomin);
 	const U32 ex = row_excl_scan(pay | sel(R.emitmin, U32(1u << 16), U32(0u)));
 	R.pm = ex + (minslen + 8u + sel(minsrle, U32(10u << 16), U32(8u << 16))); // (both halves stay far below 2^16)
+	return false;
 }
 
 // A batch: one block or two consecutive ones whose non-constant planes fill slots 0 .. nslots-1 (block 0 first).

@@ -346,7 +346,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				if (W.nblk) {
 					SlotRows R;
 					if (W.nslots)
-						slot_rows_analyse(lds, M, R);
+						slot_rows_analyse(lds, M, R, 0, W.nslots);
 					else {
 						for (int k = 0; k < 4; ++k)
 							R.sb[k] = R.sd[k] = U32(0u);
@@ -368,7 +368,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 				SlotRows R;
 				if (B.nslots)
-					slot_rows_analyse(lds, M, R);
+					slot_rows_analyse(lds, M, R, 0, B.nslots);
 				else { // only constant planes: nothing to measure
 					for (int k = 0; k < 4; ++k)
 						R.sb[k] = R.sd[k] = U32(0u);
@@ -470,13 +470,13 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			if (n0) {
 				write_slots8(lds, M, eb, mask0);
 				wave_sync();
-				slot_rows_analyse(lds, M, R0);
+				slot_rows_analyse(lds, M, R0, 0, n0);
 				incl0 = slot_pass_sizes(R0, n0, &pt0);
 			}
 			if (n1) {
 				write_slots8(lds, M, eb, mask1);
 				wave_sync();
-				slot_rows_analyse(lds, M, R1);
+				slot_rows_analyse(lds, M, R1, 0, n1);
 				incl1 = slot_pass_sizes(R1, n1, &pt1);
 			}
 			const uint32_t full = pt0 + pt1 + (8 - sc.nact);

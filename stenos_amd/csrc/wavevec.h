@@ -200,6 +200,21 @@ WV_FN U32 dot4_u8(const U32& a, uint32_t b, const U32& c)
 	}
 	return r;
 }
+// v_msad_u8: c + the sum over the four bytes of |a.byte - ref.byte|, the bytes where ref.byte is 0 left out
+WV_FN U32 msad_u8(const U32& a, const U32& ref, const U32& c)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) {
+		uint32_t s = c.l[i];
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t x = (a.l[i] >> (8 * k)) & 0xFFu, y = (ref.l[i] >> (8 * k)) & 0xFFu;
+			if (y)
+				s += x > y ? x - y : y - x;
+		}
+		r.l[i] = s;
+	}
+	return r;
+}
 WV_FN U32 mul24(const U32& a, const U32& b)
 {
 	U32 r;
@@ -578,6 +593,7 @@ WV_FN U32 mulhi(U32 a, U32 b) { return __umulhi(a, b); }
 WV_FN U32 mul24(U32 a, U32 b) { return __umul24(a, b); } // low 24 bits of both operands, full rate
 WV_FN U32 mad24(U32 a, U32 b, U32 c) { return __umul24(a, b) + c; } // (one v_mad_u32_u24)
 WV_FN U32 dot4_u8(U32 a, uint32_t b, U32 c) { return __builtin_amdgcn_udot4(a, b, c, false); } // c + sum of the four byte products
+WV_FN U32 msad_u8(U32 a, U32 ref, U32 c) { return __builtin_amdgcn_msad_u8(a, ref, c); } // c + sum of |a.byte - ref.byte| over the bytes with ref.byte != 0
 WV_FN U32 bfe(U32 x, U32 off, U32 width) { return __builtin_amdgcn_ubfe(x, off, width); }
 WV_FN U32 funnel_shr(U32 hi, U32 lo, U32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 WV_FN U32 perm_bytes(U32 hi, U32 lo, uint32_t selw) { return __builtin_amdgcn_perm(hi, lo, selw); }

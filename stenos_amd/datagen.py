@@ -53,7 +53,8 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
     sine (float64 sin(i*0.001), T=8; float32 for T=4), smooth8 (config 5b byte signal),
     mixed (per block and plane: constant / narrow / random / walk / runs), lzmix (per block: noise / dictionary /
     half dictionary / constant, 12-bit values), noise_low (noise below a slow ramp), steps (long runs of equal values),
-    slopes (piecewise linear), cycle130 (a cycle of 130 values).
+    slopes (piecewise linear), cycle130 (a cycle of 130 values), edge_noise (planes of noise with a few rows squeezed,
+    repeated or smoothed: plane sizes on both sides of the 256 bytes above which a plane is stored raw).
     """
     if n == 0:
         return np.zeros(0, dtype=np.uint8)
@@ -143,6 +144,40 @@ def generate(kind: str, T: int, n: int, seed: int = 42) -> np.ndarray:
         # 130 distinct values over and over: the mini-LZ finds every value 130 items back (distances of two bytes)
         v = (splitmix64(seed + 23, 130) >> np.uint64(2)).astype(np.int64)  # (noise in every byte: the attempt is not turned away early)
         return _le_elements(np.tile(v, n // 130 + 1)[:n], T)
+    if kind == "edge_noise":
+        # Planes of noise in which some rows of 16 bytes are made a little compressible: squeezed into a span of 60..68,
+        # given two to four repeated bytes or repeated differences, or made smooth.  A plane's size then lands within a few
+        # bytes of 256, on either side: the RAW decision (block_compress.h:1200-1204) and every shortcut around it are tested
+        # where they could go wrong.  One plane in four stays pure noise, one in eight is constant.
+        nb = (n + 255) // 256
+        rng = np.random.default_rng(seed * 7919 + T)
+        a = rng.integers(0, 256, size=(nb, T, 16, 16), dtype=np.int64)
+        plane_style = rng.integers(0, 8, size=(nb, T))
+        nrows = rng.integers(0, 5, size=(nb, T))  # rows of the plane that are touched
+        for b in range(nb):
+            for t in range(T):
+                if plane_style[b, t] == 0:
+                    a[b, t] = a[b, t, 0, 0]
+                    continue
+                if plane_style[b, t] <= 2:
+                    continue
+                for r in rng.choice(16, size=int(nrows[b, t]), replace=False):
+                    mode = int(rng.integers(0, 4))
+                    row = a[b, t, r]
+                    if mode == 0:
+                        w = int(rng.integers(60, 69))
+                        c = int(rng.integers(0, 256))
+                        row[:] = (c + row % w) & 0xFF
+                    elif mode == 1:
+                        for c in rng.choice(np.arange(1, 16), size=int(rng.integers(2, 5)), replace=False):
+                            row[c] = row[c - 1]
+                    elif mode == 2:
+                        for c in sorted(rng.choice(np.arange(2, 16), size=int(rng.integers(2, 5)), replace=False)):
+                            row[c] = (2 * row[c - 1] - row[c - 2]) & 0xFF
+                    else:
+                        row[:] = (int(row[0]) + np.arange(16) * int(rng.integers(0, 3)) + row % int(rng.integers(1, 9))) & 0xFF
+        e = a.reshape(nb, T, 256).transpose(0, 2, 1).astype(np.uint8)  # plane t of block b -> byte t of its 256 elements
+        return np.ascontiguousarray(e.reshape(nb * 256, T)[:n]).reshape(-1)
     if kind == "smooth8":
         assert T == 1
         x = (128 + 100 * np.sin(0.01 * np.arange(n))).astype(np.int64) + (u % np.uint64(5)).astype(np.int64) - 2

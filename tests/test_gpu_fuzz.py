@@ -12,7 +12,7 @@ from stenos_amd.datagen import generate
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst", "mixed", "lzmix", "noise_low", "steps", "slopes", "cycle130"]
+KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst", "mixed", "lzmix", "noise_low", "steps", "slopes", "cycle130", "edge_noise"]
 
 
 def test_random_cases_against_oracle(oracle):
