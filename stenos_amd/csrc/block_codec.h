@@ -65,11 +65,14 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 {
 	Layout L;
 	uint32_t o = 0;
-	L.in = o;
-	o += align16(256 * T + 16);
 	o += 16; // bytes of the previous block that wait for a full 16-byte group (superblock_codec.h, RunStream)
 	L.out = o;
 	o += out_capacity(T);
+	// The raw block stands behind the image: the row-lane encoder of bytesoftype 2 and 4 never fills it while it writes an image
+	// (only the mini-LZ attempt and the plane-group encoder read a block from LDS), so the image of a group of four blocks
+	// (superblock_codec.h, quad_image_bytes: up to 2 112 bytes) may run on into it -- and, for bytesoftype 2, into the row table.
+	L.in = o;
+	o += align16(256 * T + 16);
 	L.rowinfo = o;
 	o += (T < 4 ? 4 : T) * 16 * 8;
 
@@ -83,7 +86,7 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	L.lz = o;
 	uint32_t scratch = 64 * 8;
 	if (T == 2 || T == 4)
-		scratch = 4 * 256; // the four plane slots of slot_codec.h
+		scratch = 8 * 256; // the plane slots of slot_codec.h: four per pass, two passes for a group of four blocks
 	if (with_lz && T % 4 == 0 && T <= LZ_MAX_T) {
 		const uint32_t count = 256 * T / lz_width(T);
 		scratch = count * 8 > scratch ? count * 8 : scratch;

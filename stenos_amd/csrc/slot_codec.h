@@ -54,13 +54,15 @@ WV_FN SameScan scan_same_fast(const RawBlock& b, uint32_t T)
 	return s;
 }
 
-WV_FN void write_slots_fast(Lds lds, const Layout& L, const RawBlock& b, uint32_t T, uint32_t act, uint32_t slot)
+// step: distance between the slots of consecutive planes (1: side by side; 4: a group of four blocks keeps the slots of one
+// plane of its blocks side by side, superblock_codec.h)
+WV_FN void write_slots_fast(Lds lds, const Layout& L, const RawBlock& b, uint32_t T, uint32_t act, uint32_t slot, uint32_t step = 1)
 {
 	const U32 a = U32(slot2_area(L)) + lane_id() * 4u;
 	if (T == 2) {
 		if (act & 1u) {
 			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(b.e.y, b.e.x, 0x06040200u), pred_all(true));
-			++slot;
+			slot += step;
 		}
 		if (act & 2u)
 			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(b.e.y, b.e.x, 0x07050301u), pred_all(true));
@@ -71,18 +73,18 @@ WV_FN void write_slots_fast(Lds lds, const Layout& L, const RawBlock& b, uint32_
 		const U32 t0 = perm_bytes(b.e.y, b.e.x, 0x05010400u), t2 = perm_bytes(b.e.w, b.e.z, 0x05010400u); // bytes 0 and 1 of two elements each
 		if (act & 1u) {
 			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t2, t0, 0x05040100u), pred_all(true));
-			++slot;
+			slot += step;
 		}
 		if (act & 2u) {
 			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t2, t0, 0x07060302u), pred_all(true));
-			++slot;
+			slot += step;
 		}
 	}
 	if (act & 12u) {
 		const U32 t1 = perm_bytes(b.e.y, b.e.x, 0x07030602u), t3 = perm_bytes(b.e.w, b.e.z, 0x07030602u); // bytes 2 and 3
 		if (act & 4u) {
 			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t3, t1, 0x05040100u), pred_all(true));
-			++slot;
+			slot += step;
 		}
 		if (act & 8u)
 			lds_st32(lds, a + slot * SLOT2_BYTES, perm_bytes(t3, t1, 0x07060302u), pred_all(true));
@@ -364,7 +366,7 @@ WV_FN U32 pack4v(const U32& x, const U32& bits)
 // with 8 bits, no minimum and the bytes as they came.  Lanes that write nothing (run-length rows, rows of 0 bits, unused
 // slots) OR whatever they computed into a dump behind the image (the slot area: its rows are in registers by now), so
 // nothing has to be masked to zero for them.
-WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const Pred& rawrow, const Pred& packed, const U32& bits, const U32& rbase)
+WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const Pred& rawrow, const Pred& packed, const U32& bits, const U32& rbase, uint32_t scr = 0)
 {
 	const U32 lane = lane_id();
 	const U32 H(0x80808080u);
@@ -378,7 +380,7 @@ WV_FN void emit_row_payload(Lds out, const Layout& L, const SlotRows& R, const P
 	U32 s0lo, s0hi, s1lo, s1hi;
 	shl64(pk[1], sh4, s0lo, s0hi);
 	shl64(pk[3], sh4, s1lo, s1hi);
-	const U32 dump = U32(slot2_area(L) - L.out) + lane * 16u;
+	const U32 dump = U32(slot2_area(L) + scr - L.out) + lane * 16u;
 	const Pred anyw = rawrow | packed;
 	lds_put_bytes8(out, sel(anyw, rbase, dump), s0lo | pk[0], s0hi);
 	lds_put_bytes8(out, sel(anyw, rbase + ebits, dump), s1lo | pk[2], s1hi);
@@ -401,13 +403,16 @@ WV_FN void slot_write_rle_lut(Lds lds, const Layout& L)
 
 // The rows of the slots into the zeroed image, once every slot knows where its plane starts (pbase, from the image's start):
 // header nibbles, minima, the mask of repeated minima, payloads (block_compress.h:739-806).  Shared by the three batch forms.
-WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, const Pred& valid, const U32& pbase)
+// scr: which KiB of the slot area serves as scratch -- the dump of the lanes with nothing to write, the hand-over of the
+// run-length rows -- (0: the pass's own slots, whose rows are in registers; a group of four blocks names the slots of its
+// second pass, the first one's being read again later)
+WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, const Pred& valid, const U32& pbase, uint32_t scr = 0)
 {
 	const U32 lane = lane_id();
 	const U32 r = lane & 15u;
 	const U32 H(0x80808080u);
 	Lds out = lds + L.out;
-	const U32 own = U32(slot2_area(L) - L.out) + lane * 16u; // where lanes with nothing to write OR what they have (outside the image)
+	const U32 own = U32(slot2_area(L) + scr - L.out) + lane * 16u; // where lanes with nothing to write OR what they have (outside the image)
 	WV_MARK("emit_rowlanes");
 	const U32 hdr = R.hdr();
 	const Pred israw = valid & (R.type() == U32(PLANE_RAW));
@@ -439,7 +444,7 @@ WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, cons
 	const Pred packed = normal & !is15 & !isr & (bits != U32(0u));
 	const Pred rle = normal & isr;
 	const U32 rbase = pbase + sel(israw, r * 16u, R.pm & 0xFFFFu);
-	emit_row_payload(out, L, R, rawrow, packed, bits, rbase);
+	emit_row_payload(out, L, R, rawrow, packed, bits, rbase, scr);
 	// rle / delta-rle rows (:258-265, 285-293): [mask16][literals]
 	if (any(rle)) {
 		// Few rows of a pass are run-length rows (one or two per block of smooth floats), but a loop over the row's four
@@ -452,7 +457,7 @@ WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, cons
 		const uint64_t rows = ballot(rle);
 		const uint32_t n = (uint32_t)__builtin_popcountll(rows);
 		const U32 rank = lane_rank(rows);
-		const uint32_t area = slot2_area(L); // entry i, 32 bytes: [payload offset][-][-][byte in front][the row's 16 bytes]
+		const uint32_t area = slot2_area(L) + scr; // entry i, 32 bytes: [payload offset][-][-][byte in front][the row's 16 bytes]
 		U128 d;
 		d.x = sel(is7, R.sb[0], R.sd[0]), d.y = sel(is7, R.sb[1], R.sd[1]), d.z = sel(is7, R.sb[2], R.sd[2]), d.w = sel(is7, R.sb[3], R.sd[3]);
 		// in front of a row of values: the last byte of the row above (:268-275); of a row of differences: no difference (:248-255)
@@ -615,6 +620,79 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 		return;
 	}
 	slot_rows_emit_rows(lds, L, R, P.valid, pbase);
+}
+
+// ---- groups of four blocks (bytesoftype 2 and 4) --------------------------------------------------------------------------
+// Four consecutive blocks in which the same two planes are not constant -- 12-bit integers in 32-bit elements, every block
+// of 16-bit samples -- are analysed plane by plane: the first pass takes the lower of the two planes of all four blocks, the
+// second pass the upper one.  Planes of the same kind then share a pass: the noise in the low byte of such data is proven RAW
+// (slot_rows_analyse) and written as it came, sixteen bytes per lane, and every lane of the other pass packs a row.  Taken
+// block by block -- a noise plane and a coded plane of two blocks per pass -- every pass paid the whole analysis and the whole
+// packing with half of its lanes.  Both passes are analysed before anything is written (a block's size is the sum of both),
+// then written one behind the other; the rows of the first pass are read again from their slots for that.
+constexpr uint32_t GROUP4_IMAGE_BYTES = 2112; // 15 waiting bytes + 4 x (2 + 2 + 2 x 256) and the slack of an 8-byte OR, in 16-byte groups
+
+// the image of a group, zeroed, with the waiting bytes of the stream in front (block_codec.h, image_reset_fixed)
+WV_FN void image_reset_group4(Lds lds, const Layout& L)
+{
+	const U32 lane = lane_id();
+	U128 z;
+	z.x = z.y = z.z = z.w = U32(0u);
+	lds_st128(lds, U32(L.out) + lane * 16u, z, pred_all(true));
+	lds_st128(lds, U32(L.out + 1024u) + lane * 16u, z, pred_all(true));
+	lds_st128(lds, U32(L.out + 2048u) + lane * 16u, z, lane * 16u < U32(GROUP4_IMAGE_BYTES - 2048u));
+	wave_sync();
+	const Pred p = lane < U32(4u);
+	const U32 a = sel(p, lane, U32(0u)) * 4u;
+	lds_st32(lds, U32(L.out) + a, lds_ld32(lds, U32(L.out - 16u) + a), p);
+	wave_sync();
+}
+
+// the rows of a pass back from their slots: the bytes, and their differences when a row codes differences
+WV_FN void slot_rows_reload(Lds lds, const Layout& L, SlotRows& R, uint32_t slot_off, bool deltas)
+{
+	const U32 lane = lane_id();
+	const U32 H(0x80808080u);
+	const U128 v = lds_ld128(lds, U32(slot2_area(L) + slot_off) + lane * 16u);
+	R.sb[0] = v.x ^ H;
+	R.sb[1] = v.y ^ H;
+	R.sb[2] = v.z ^ H;
+	R.sb[3] = v.w ^ H;
+	if (deltas) {
+		const U32 above = row_shr(R.sb[3], 1, 0x80808080u);
+		R.sd[0] = biased_sub(R.sb[0], prev_bytes(R.sb[0], above));
+		for (int k = 1; k < 4; ++k)
+			R.sd[k] = biased_sub(R.sb[k], prev_bytes(R.sb[k], R.sb[k - 1]));
+	}
+	else
+		R.sd[0] = R.sd[1] = R.sd[2] = R.sd[3] = U32(0u);
+}
+
+// Type nibbles and the bytes of the constant planes of the four blocks of a group (block_compress.h:747-750, 1246-1257): in the
+// sixteen lanes of block q, lane 0 writes the type of plane k0, lane 1 that of plane k1, lanes 2 and 3 (bytesoftype 4) the bytes
+// of the two constant planes.  bbase: the block's start in the image; ts0, ts1: size | type << 16 of the block's two planes;
+// firstv: an element of the block (any: the planes in question are constant).
+WV_FN void group4_emit_heads(Lds lds, const Layout& L, uint32_t T, uint32_t k0, uint32_t k1, const U32& bbase, const U32& ts0, const U32& ts1, const U32& firstv, uint32_t scr)
+{
+	const U32 lane = lane_id();
+	const U32 r = lane & 15u;
+	Lds out = lds + L.out;
+	const U32 own = U32(slot2_area(L) + scr - L.out) + lane * 16u;
+	const uint32_t hs = header_bytes(T);
+	// the planes the lanes 0..3 of a block stand for: k0, k1 and (bytesoftype 4) the two others, ascending
+	uint32_t rest = 15u & ~((1u << k0) | (1u << k1));
+	const uint32_t j0 = (uint32_t)__builtin_ctz(rest | 16u);
+	rest &= rest - 1u;
+	const uint32_t j1 = (uint32_t)__builtin_ctz(rest | 16u);
+	const U32 plane = (U32(k0 | (k1 << 8) | (j0 << 16) | (j1 << 24)) >> (r << 3)) & 0xFFu;
+	const Pred nib = r < U32(2u);
+	const U32 type = sel(r == U32(0u), ts0, ts1) >> 16;
+	// a constant plane stands behind the constant planes and the coded planes in front of it
+	const Pred after0 = plane > U32(k0), after1 = plane > U32(k1);
+	const U32 where = bbase + U32(hs) + plane - sel(after0, U32(1u), U32(0u)) - sel(after1, U32(1u), U32(0u)) + sel(after0, ts0 & 0xFFFFu, U32(0u)) +
+			  sel(after1, ts1 & 0xFFFFu, U32(0u));
+	const U32 byte = (firstv >> (plane << 3)) & 0xFFu;
+	put_small(out, sel(nib, bbase * 8u + plane * 4u, where * 8u), sel(nib, type, byte), r < U32(T), own);
 }
 
 // ---- bytesoftype 8 -----------------------------------------------------------------------------------------------------

@@ -11,6 +11,14 @@
 
 namespace codec {
 
+#ifdef WV_HOST_EMULATION
+inline uint64_t& emul_group4_count()
+{
+	static uint64_t n = 0;
+	return n;
+}
+#endif
+
 // ---- HBM <-> LDS copies by one wave ---------------------------------------------------------------
 
 #ifdef WV_PREDICATE_BRANCHES // (the encoders: predicates as branches, wavevec.h)
@@ -227,6 +235,92 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 		// After a wide batch the next pass probably is one too and asks for its four blocks at once: passes that start below
 		// this block number do (0: none).
 		uint32_t wide_ahead = 0;
+		// Four blocks with the same two planes that are not constant, taken plane by plane (slot_codec.h, "groups of four
+		// blocks").  False: the blocks are not of that shape, or one of them may go to the mini-LZ -- nothing has been written,
+		// the pass below takes them.  try_group: the last blocks seen had the shape (or nothing is known yet).
+		bool try_group = true;
+		auto group4 = [&]() __attribute__((always_inline)) -> bool {
+			const uint8_t* a = src + (uint64_t)i * bs;
+			WV_MARK("g4_load");
+			const RawBlock e0 = load_raw_block(a, T), e1 = load_raw_block(a + bs, T), e2 = load_raw_block(a + 2 * bs, T), e3 = load_raw_block(a + 3 * bs, T);
+			const Layout M = sink.at(L);
+			WV_MARK("g4_front");
+			const SameScan s0 = scan_same_fast(e0, T);
+			if (s0.nact != 2) {
+				try_group = false;
+				return false;
+			}
+			const SameScan s1 = scan_same_fast(e1, T), s2 = scan_same_fast(e2, T), s3 = scan_same_fast(e3, T);
+			if (s1.act != s0.act || s2.act != s0.act || s3.act != s0.act) {
+				try_group = false;
+				return false;
+			}
+			const uint32_t k0 = (uint32_t)__builtin_ctz(s0.act), k1 = 31u - (uint32_t)__builtin_clz(s0.act);
+			uint32_t keys0 = 0, keys1 = 0, keys2 = 0, keys3 = 0; // (first rejection test of the mini-LZ, as in the pass below)
+			if (T == 4) {
+				keys0 = lz_distinct_keys_fast<2>(lds, M, e0.e);
+				keys1 = lz_distinct_keys_fast<2>(lds, M, e1.e);
+				keys2 = lz_distinct_keys_fast<2>(lds, M, e2.e);
+				keys3 = lz_distinct_keys_fast<2>(lds, M, e3.e);
+			}
+			// plane k0 of block q -> slot q, plane k1 -> slot 4 + q
+			write_slots_fast(lds, M, e0, T, s0.act, 0, 4);
+			write_slots_fast(lds, M, e1, T, s0.act, 1, 4);
+			write_slots_fast(lds, M, e2, T, s0.act, 2, 4);
+			write_slots_fast(lds, M, e3, T, s0.act, 3, 4);
+			// an element of its block for the sixteen lanes of each block (the bytes of the constant planes)
+			const U32 firstv = T == 4 ? row_select4v(e0.e.x, e1.e.x, e2.e.x, e3.e.x) : U32(0u);
+			if (sink.raw_to) { // (measured only, probably a copy: the raw bytes go where the copy would put them)
+				sink.raw(e0, T, i);
+				sink.raw(e1, T, i + 1);
+				sink.raw(e2, T, i + 2);
+				sink.raw(e3, T, i + 3);
+			}
+			wave_sync();
+			SlotRows R;
+			WV_MARK("g4_pass0");
+			const bool raw0 = slot_rows_analyse(lds, M, R, 0, 4);
+			const U32 ts0 = R.ts, hm0 = R.hm, pm0 = R.pm;
+			const Pred emitmin0 = R.emitmin, eq0 = R.eq;
+			WV_MARK("g4_pass1");
+			slot_rows_analyse(lds, M, R, 1024, 4);
+			WV_MARK("g4_sizes");
+			const U32 bsz = (ts0 & 0xFFFFu) + R.size() + U32(hs + T - 2u); // the block of the lane's slot
+			U32 incl = bsz + scan_source(bsz, 4, 0u);
+			incl = incl + scan_source(incl, 5, 0u);
+			const uint32_t total = readlane(incl, 63);
+			if (T == 4) {
+				// a block the mini-LZ may take (block_compress.h:1210-1221): the pass below decides and encodes it
+				const uint32_t f0 = readlane(bsz, 0) - hs, f1 = readlane(bsz, 16) - hs, f2 = readlane(bsz, 32) - hs, f3 = readlane(bsz, 48) - hs;
+				if ((f0 * 3 > bs && lz_precheck_passes(T, keys0, f0)) || (f1 * 3 > bs && lz_precheck_passes(T, keys1, f1)) ||
+				    (f2 * 3 > bs && lz_precheck_passes(T, keys2, f2)) || (f3 * 3 > bs && lz_precheck_passes(T, keys3, f3))) {
+					try_group = false;
+					return false;
+				}
+			}
+			if (sink.writes) {
+				WV_MARK("g4_emit1");
+				image_reset_group4(lds, M);
+				const U32 bbase = U32(sink.base()) + incl - bsz;
+				// the second pass first: its rows are in registers; the slots of that pass are the scratch of both emissions
+				slot_rows_emit_rows(lds, M, R, pred_all(true), bbase + U32(hs + k1 - 1u) + (ts0 & 0xFFFFu), 1024);
+				group4_emit_heads(lds, M, T, k0, k1, bbase, ts0, R.ts, firstv, 1024);
+				WV_MARK("g4_emit0");
+				slot_rows_reload(lds, M, R, 0, !raw0);
+				R.ts = ts0, R.hm = hm0, R.pm = pm0;
+				R.emitmin = emitmin0, R.eq = eq0;
+				slot_rows_emit_rows(lds, M, R, pred_all(true), bbase + U32(hs + k0), 1024);
+			}
+			WV_MARK("g4_append");
+			sink.append(lds, M, total);
+			WV_MARK("g4_end");
+#ifdef WV_HOST_EMULATION
+			++emul_group4_count(); // (tests/emul: the tests assert that the inputs meant for this path take it)
+#endif
+			i += 4;
+			hook();
+			return true;
+		};
 		// One pass.  has_b (a type: known where the pass is compiled): a second block follows in the run -- every pass but a
 		// last single block, which gets a copy of the pass without the tests for it.
 		auto pass = [&](auto has_b_t) __attribute__((always_inline)) {
@@ -301,6 +395,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				if (nblk > 1)
 					write_slots_fast(lds, M, eb, T, B.act[1], B.nact0);
 				B.nblk = nblk;
+				// (the next four blocks probably look like these two: worth a try as a group, below)
+				try_group = nblk == 2 && B.act[0] == B.act[1] && B.nact0 == 2;
 				// Two blocks with at most one non-constant plane each leave slots free: the blocks behind them move in while
 				// they have at most one such plane themselves (a wide batch, slot_codec.h).
 				SlotBatch4 W;
@@ -412,6 +508,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					return;
 				}
 			}
+			try_group = false; // (blocks the mini-LZ may take are encoded one at a time)
 			// a mini-LZ attempt, one block at a time (the raw bytes of a measured superblock have been put in place already,
 			// above).  The candidates' sizes without the mini-LZ are known from the pass -- it left them in the plane table's
 			// place, so that nothing of this rare path is alive in the pass --: the attempt needs nothing else, and the general
@@ -432,8 +529,14 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			}
 			i += nblk;
 		};
-		while (i + 1 < nblocks)
+		while (i + 1 < nblocks) {
+			if (try_group && i + 3 < nblocks) {
+				WV_NESTED();
+				if (group4())
+					continue;
+			}
 			pass(std::true_type());
+		}
 		if (i < nblocks)
 			pass(std::false_type());
 		return;

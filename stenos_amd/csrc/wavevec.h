@@ -338,6 +338,13 @@ WV_FN U32 row_select4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = i < 16 ? a0 : (i < 32 ? a1 : (i < 48 ? a2 : a3));
 	return r;
 }
+// lanes 16k .. 16k+15 keep their own value of a_k (four vectors)
+WV_FN U32 row_select4v(const U32& a0, const U32& a1, const U32& a2, const U32& a3)
+{
+	U32 r;
+	for (int i = 0; i < WAVE; ++i) r.l[i] = i < 16 ? a0.l[i] : (i < 32 ? a1.l[i] : (i < 48 ? a2.l[i] : a3.l[i]));
+	return r;
+}
 
 // ---- LDS (byte addressed; 32-bit accesses must be 4-byte aligned unless named *_unaligned) ----
 WV_FN U32 lds_ld8(Lds m, const U32& a)
@@ -703,6 +710,25 @@ WV_FN U32 row_select4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
 		     "s_mov_b64 exec, %1"
 		     : "=&v"(v), "=&s"(save)
 		     : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(0xFFFFFFFFFFFF0000ull), "s"(0xFFFFFFFF00000000ull), "s"(0xFFFF000000000000ull)
+		     : "scc");
+	return v;
+}
+// lanes 16k .. 16k+15 keep their own value of a_k (four vectors): the same four moves
+WV_FN U32 row_select4v(U32 a0, U32 a1, U32 a2, U32 a3)
+{
+	U32 v;
+	uint64_t save;
+	asm volatile("s_mov_b64 %1, exec\n"
+		     "v_mov_b32 %0, %2\n"
+		     "s_and_b64 exec, %1, %6\n"
+		     "v_mov_b32 %0, %3\n"
+		     "s_and_b64 exec, %1, %7\n"
+		     "v_mov_b32 %0, %4\n"
+		     "s_and_b64 exec, %1, %8\n"
+		     "v_mov_b32 %0, %5\n"
+		     "s_mov_b64 exec, %1"
+		     : "=&v"(v), "=&s"(save)
+		     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(0xFFFFFFFFFFFF0000ull), "s"(0xFFFFFFFF00000000ull), "s"(0xFFFF000000000000ull)
 		     : "scc");
 	return v;
 }
