@@ -16,12 +16,13 @@ With --gpus N every rank owns its own 8 GiB superblock range of an 8*N GiB array
 data-path collective in the timed region); the gather of the compressed segments to rank 0 and the sharded
 decode are run and timed afterwards ("sharded_exchange").
 Outside the timed region at N=1: the reference's CPU path on a 1 GiB prefix ("cpu_baseline"), a byte-for-byte
-comparison of the GPU frame with the reference's frame of that prefix ("parity_prefix_bytes"), the host-pointer
+comparison of the WHOLE GPU frame with the reference's frames of its 1 GiB slices ("parity_bytes"), the host-pointer
 ABI end to end ("host_pointer"), the other configurations of BASELINE.json ("other_configs"), and the rate of the
 runtime's own device-to-device copy on the box ("roofline.device_copy": context for the fractions of the nominal peak).
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run.
-Prints ONE JSON line on rank 0.
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either through torch.distributed.run (one rank per GPU,
+RANK / WORLD_SIZE in the environment) or plainly: without RANK the script starts the N ranks itself as a child process and
+relays rank 0's line.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -191,7 +192,8 @@ def run_workload(st, torch, src, T, steps, warmup, dist, world, blocking=False):
 CONFIGS = {
     # name: (datagen kind, bytesoftype, description)
     "int32": ("rand12", 4, "configs[1]: {gib:g} GiB int32 per GPU, bytesof=4, level 1, uniform 12-bit values (splitmix64 seed 42, u & 0xFFF)"),
-    "int16": ("walk", 2, "configs[3] shard: {gib:g} GiB int16 random walk per GPU (x += u % 17 - 8, splitmix64 seed 7 + rank), bytesof=2, level 1"),
+    "int16": ("walk", 2, "configs[3] shard: {gib:g} GiB int16 random walk per GPU (x += u % 17 - 8), bytesof=2, level 1; every rank draws a walk of its own "
+              "(splitmix64 seed 7 + rank): N independent series of {gib:g} GiB, not one series of N x {gib:g} GiB cut in N"),
     "double": ("sine", 8, "configs[2] at level 1: {gib:g} GiB double sin(i * 0.001) per GPU, bytesof=8"),
 }
 
@@ -251,6 +253,9 @@ def measure_other(name, torch, dist, dev, with_cpu):
         nbytes = min((cpu_mib << 20) + 4000 * T, nb)
         sample = src[:nbytes].cpu().numpy()
         e["cpu_baseline"] = cpu_baseline(sample, T, f"first {cpu_mib} MiB + {4000 * T} B of the same workload, same level, best of 3", level=level, reps=3)
+        if level == 1 and T > 1:  # the whole frame against the reference's, slice by slice (outside the timed region)
+            e["parity_bytes"] = reference_frame_parity(st, torch, src, T)
+            e["parity_frame_bytes"] = int(r["csize"])
     st.close()
     del src
     torch.cuda.empty_cache()
@@ -305,10 +310,12 @@ def device_copy_rate(torch, dev, nbytes=2 << 30, reps=5):
             "note": f"torch copy_ of {nbytes >> 30} GiB between two device buffers (the runtime's copy kernel), read + written bytes: the practical ceiling of a read + write stream here"}
 
 
-def reference_prefix_parity(st, torch, src, T, nprefix):
-    """Byte-for-byte check at benchmark scale, outside the timed region: the reference's frame of the first `nprefix` bytes
-    of the workload (whole superblocks) against the same superblocks of the GPU's frame of the whole array -- superblocks
-    are coded independently, so the streams must be identical.  Returns the compared frame bytes or None."""
+def reference_frame_parity(st, torch, src, T, slice_bytes=1 << 30):
+    """Byte-for-byte check of the WHOLE frame at benchmark scale, outside the timed region: superblocks are coded independently,
+    so the reference's frame of a slice of whole superblocks must equal the same superblocks of the GPU's frame of the whole
+    array.  The array is taken in slices of 1 GiB (host memory stays bounded; the reference needs about half a second per
+    slice with all cores).  Returns the compared frame bytes (the frame minus its 8-byte header), or None without the
+    compiled reference."""
     import numpy as np
 
     from _libs import load_ref, np_ptr
@@ -316,18 +323,35 @@ def reference_prefix_parity(st, torch, src, T, nprefix):
     ref = load_ref(det=False)
     if ref is None:
         return None
-    sample = src[:nprefix].cpu().numpy()
-    exp = np.zeros(ref.stenos_bound(nprefix), dtype=np.uint8)
+    nbytes = src.numel()
+    sb = 131072 // (256 * T) * 256 * T
+    slice_bytes = max(sb, slice_bytes // sb * sb)
+    dst = torch.empty(st.bound(nbytes), dtype=torch.uint8, device=src.device)
+    csize = st.compress(src, T, dst)
+    idx_ptr, nsb = st.last_index()
+    assert idx_ptr and nsb == (nbytes + sb - 1) // sb
+    index = torch.empty(nsb + 1, dtype=torch.int64)
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(index.data_ptr()), ctypes.c_void_p(idx_ptr), ctypes.c_size_t((nsb + 1) * 8), 2) == 0
     ctx = ref.stenos_make_context()
     ref.stenos_set_level(ctx, 1)
     ref.stenos_set_threads(ctx, os.cpu_count() or 1)
-    r = ref.stenos_compress_generic(ctx, np_ptr(sample), T, nprefix, np_ptr(exp), exp.nbytes)
+    exp = np.zeros(ref.stenos_bound(slice_bytes), dtype=np.uint8)
+    compared = 0
+    for begin in range(0, nbytes, slice_bytes):
+        n = min(slice_bytes, nbytes - begin)
+        sample = src[begin:begin + n].cpu().numpy()
+        r = ref.stenos_compress_generic(ctx, np_ptr(sample), T, n, np_ptr(exp), exp.nbytes)
+        assert r < (1 << 63), "the reference failed on a slice"
+        s0, s1 = begin // sb, (begin + n + sb - 1) // sb
+        o0, o1 = int(index[s0]), int(index[s1])
+        assert o1 - o0 == r - 8, f"slice at {begin}: {o1 - o0} frame bytes on the GPU, {r - 8} from the reference"
+        got = dst[o0:o1].cpu().numpy()
+        assert np.array_equal(got, exp[8:r]), f"GPU frame differs from the reference's frame in the slice at {begin}"
+        compared += r - 8
     ref.stenos_destroy_context(ctx)
-    dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device=src.device)
-    st.compress(src, T, dst)
-    got = dst[8:r].cpu().numpy()
-    assert np.array_equal(got, exp[8:r]), "GPU frame differs from the reference's frame on the common superblocks"
-    return int(r - 8)
+    assert compared == csize - 8
+    return int(compared)
 
 
 def host_pointer_rate(T, sample):
@@ -375,14 +399,42 @@ def host_pointer_rate(T, sample):
     return res
 
 
+def launch_ranks(args):
+    """python bench.py --gpus N without an outer torch.distributed.run: start the N ranks as a CHILD process (this process has
+    not touched the GPU -- nothing is imported that would -- and never execs), relay rank 0's JSON line, return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:])
+        sys.stderr.write(f"\nbench.py: the {args.gpus}-rank child exited with {p.returncode}" + ("" if line else " and printed no result line") + "\n")
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
 
     # one process per GPU; STENOS_BENCH_ONE_DEVICE=1 (test rigs with a single GPU) puts every rank on cuda:0
@@ -477,7 +529,9 @@ def main():
         sample_bytes = (mib << 20) + 4000 if (mib << 20) + 4000 <= nbytes else nbytes  # not a superblock multiple: the reference decoder rejects those
         sample = src[:sample_bytes].cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(sample, T, f"first {mib} MiB + 4000 B of the same workload, best of 5")
-        out["parity_prefix_bytes"] = reference_prefix_parity(st, torch, src, T, mib << 20)
+        # the whole frame against the reference's, slice by slice (parity_prefix_bytes: the name of rounds 2-4, when it was a prefix)
+        out["parity_bytes"] = out["parity_prefix_bytes"] = reference_frame_parity(st, torch, src, T)
+        out["parity_frame_bytes"] = int(r["csize"])
         out["host_pointer"] = host_pointer_rate(T, sample)
         del sample
     if world == 1 and args.config == "int32" and not args.kind and not args.no_other_configs:

@@ -76,9 +76,6 @@ STENOS_EXPORT size_t stenos_hip_delta_inv(const void* d_src, void* d_dst, size_t
  * stenos_hip_last_devices returns how many devices the last host-pointer call on ctx used (1: the single-device path). */
 STENOS_EXPORT void stenos_hip_set_devices(stenos_context* ctx, int devices);
 STENOS_EXPORT int stenos_hip_last_devices(stenos_context* ctx);
-/* Tests only: share_current_device != 0 lets the "devices" of such a call all stand for the current device (one-GPU
- * boxes); fail_lane >= 0 keeps that lane from running, as if its device could not be made current (-1: none). */
-STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane);
 
 /* Levels >= 2 (and bytesoftype 1) run a strategy layer on the host around the GPU passes (LZ4-dry estimates, zstd).  Wall
  * time per stage in milliseconds, summed over the calls on ctx since the last reset: out[0] GPU block pass + verdicts and
@@ -87,15 +84,23 @@ STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_
  * superblocks.  Transfers that are hidden behind zstd do not show.  Returns the number of stages; reset != 0 clears the sums. */
 STENOS_EXPORT int stenos_hip_stage_ms(stenos_context* ctx, double* out, int n, int reset);
 
-/* Tests only: serial != 0 makes frames that come without an index be walked by one lane (the serial walk that the
- * parallel one of walk.h is proven against, and falls back to).  Returns whether the last parallel walk on ctx fell back
- * to the serial one (1), did not (0), or there was none (-1). */
-STENOS_EXPORT int stenos_hip_test_walk(stenos_context* ctx, int serial);
-
 /* The fused encoder's waits for frame offsets are bounded; a launch that gives up (never observed) is redone without that
- * kernel instead of failing the call.  Returns how often that has happened on ctx.  inject > 0 (tests): the next
- * `inject` fused launches are treated as if they had given up. */
-STENOS_EXPORT int stenos_hip_fused_fallbacks(stenos_context* ctx, int inject);
+ * kernel instead of failing the call.  Returns how often that has happened on ctx. */
+STENOS_EXPORT int stenos_hip_fused_fallbacks(stenos_context* ctx);
+
+#ifdef STENOS_TEST_HOOKS
+/* Switches for the test suite.  They exist only in the build the tests make for themselves (tests/hooks/Makefile,
+ * -DSTENOS_TEST_HOOKS: tests/hooks/libstenos_hooks.so); libstenos.so neither declares nor exports them.
+ * stenos_hip_test_lanes: share_current_device != 0 lets the "devices" of a multi-device call all stand for the current device
+ * (one-GPU boxes); fail_lane >= 0 keeps that lane from running, as if its device could not be made current (-1: none).
+ * stenos_hip_test_walk: serial != 0 makes frames that come without an index be walked by one lane (the serial walk that the
+ * parallel one of walk.h is proven against, and falls back to); returns whether the last parallel walk on ctx fell back to
+ * the serial one (1), did not (0), or there was none (-1).
+ * stenos_hip_test_fused_timeouts: the next n fused launches are treated as if they had given up waiting. */
+STENOS_EXPORT void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fail_lane);
+STENOS_EXPORT int stenos_hip_test_walk(stenos_context* ctx, int serial);
+STENOS_EXPORT void stenos_hip_test_fused_timeouts(stenos_context* ctx, int n);
+#endif
 
 /* Kernel timing for benchmarks: when enabled, HIP events are recorded on the job's stream around the
  * dominant kernel of each direction: which = 0, the encoder (encode_superblocks, the fused kernel; encode_blocks

@@ -76,10 +76,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "stenos_hip_device_count": (c_int, []),
         "stenos_hip_last_devices": (c_int, [vp]),
         "stenos_hip_set_devices": (None, [vp, c_int]),
-        "stenos_hip_test_lanes": (None, [vp, c_int, c_int]),
-        "stenos_hip_test_walk": (c_int, [vp, c_int]),
         "stenos_hip_stage_ms": (c_int, [vp, ctypes.POINTER(ctypes.c_double), c_int, c_int]),
-        "stenos_hip_fused_fallbacks": (c_int, [vp, c_int]),
+        "stenos_hip_fused_fallbacks": (c_int, [vp]),
         "stenos_hip_workspace_bytes": (sz, [sz, sz]),
         "stenos_hip_compress": (sz, [vp, vp, sz, sz, vp, sz, vp]),
         "stenos_hip_compress_async": (sz, [vp, vp, sz, sz, vp, sz, vp]),
@@ -100,6 +98,14 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     lib._stenos_symbols = tuple(sigs)
+    # the test suite's own build (tests/hooks/Makefile, -DSTENOS_TEST_HOOKS) has three switches more; libstenos.so has none
+    hooks = {"stenos_hip_test_lanes": (None, [vp, c_int, c_int]), "stenos_hip_test_walk": (c_int, [vp, c_int]), "stenos_hip_test_fused_timeouts": (None, [vp, c_int])}
+    lib._stenos_test_hooks = all(hasattr(lib, name) for name in hooks)
+    if lib._stenos_test_hooks:
+        for name, (res, args) in hooks.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     return lib
 
 

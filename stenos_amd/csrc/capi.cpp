@@ -235,7 +235,7 @@ struct stenos_context_s {
 	DevBuf qprod, shuf, mid0, mid1;                  // levels >= 2: ratio checkpoints, shuffled input, plane middles (raw / delta'd)
 	DevBuf walk;                                     // segments of the parallel header walk (walk.h)
 	DevBuf dslots, dtab;                             // levels >= 2, device destinations: zstd output slots of two batches and their offset / size tables
-	bool test_serial_walk = false;                   // stenos_hip_test_walk: frames without an index are walked by one lane
+	bool test_serial_walk = false;                   // (only the test build can set it) stenos_hip_test_walk: frames without an index are walked by one lane
 	DevBuf wide;                                     // bytesoftype above 64: scratch of the HBM-resident kernels (kernels_wide.hip)
 	DevBuf misc;                                     // [0,8) total, [8,12) decode status, [12,16) encode status, [16,20) first flagged, [20,24) unused, [24,32) scan carry, [64,320) override payload
 	HostBuf h_in, h_out, h_blocks, h_shuf, h_mid0, h_mid1, h_stage, h_tab; // host staging of the strategy layer
@@ -266,7 +266,7 @@ struct stenos_context_s {
 	size_t job_T = 0, job_bytes = 0;
 	bool no_fused = false;
 	int fused_fallbacks = 0;      // times that happened (stenos_hip_fused_fallbacks)
-	int inject_chain_timeout = 0; // test hook: the next n fused launches are treated as if they had given up
+	int inject_chain_timeout = 0; // (only the test build can set it, stenos_hip_test_fused_timeouts) the next n fused launches are treated as if they had given up
 	int device = -1; // the device the buffers above live on (the one that was current when they were first needed)
 	// host-pointer calls with stenos_set_threads(ctx, n > 1): one child context per further device (or per stand-in lane),
 	// used from a host thread of its own (multi_device below)
@@ -2489,6 +2489,8 @@ int stenos_hip_stage_ms(stenos_context* ctx, double* out, int n, int reset)
 			v = 0;
 	return (int)STAGE_COUNT;
 }
+int stenos_hip_fused_fallbacks(stenos_context* ctx) { return ctx ? ctx->fused_fallbacks : 0; }
+#ifdef STENOS_TEST_HOOKS // (the test suite's own build only: tests/hooks/Makefile)
 int stenos_hip_test_walk(stenos_context* ctx, int serial)
 {
 	if (!ctx)
@@ -2508,14 +2510,12 @@ void stenos_hip_test_lanes(stenos_context* ctx, int share_current_device, int fa
 	ctx->test_lanes_share_device = share_current_device != 0;
 	ctx->test_fail_lane = fail_lane;
 }
-int stenos_hip_fused_fallbacks(stenos_context* ctx, int inject)
+void stenos_hip_test_fused_timeouts(stenos_context* ctx, int n)
 {
-	if (!ctx)
-		return 0;
-	if (inject > 0)
-		ctx->inject_chain_timeout = inject;
-	return ctx->fused_fallbacks;
+	if (ctx && n > 0)
+		ctx->inject_chain_timeout = n;
 }
+#endif
 int stenos_hip_device_count(void)
 {
 	int n = 0;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64, decode_occupancy(TT)) void decode_superblocks(D
 			status_or(a.status, DECODE_STATUS_INVALID);
 			return;
 		}
-		copy_g2g_wide<STENOS_DECODE_COPY_ROUNDS>(out, payload, csize); // (this kernel has registers to spare: more loads in flight per trip)
+		copy_g2g_wide<COPY_ROUNDS>(out, payload, csize); // (this kernel has registers to spare: more loads in flight per trip)
 	}
 	else if (code >= 2 && code <= 5) { // zstd based codes are finished by the host
 		status_or(a.status, DECODE_STATUS_HOST_CODES);

@@ -76,25 +76,11 @@ __global__ __launch_bounds__(256) void init_job(uint8_t* __restrict__ misc, uint
 // ends.  A poll counter bounds them anyway: a wait that would hang the device is reported as an error instead.
 constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;
 constexpr uint64_t CHAIN_FAILED = ~0ull;
-#ifndef STENOS_FUSED_OCCUPANCY
-#define STENOS_FUSED_OCCUPANCY 8
-#endif
-constexpr uint32_t FUSED_OCCUPANCY = STENOS_FUSED_OCCUPANCY;
 // Waves per SIMD the kernel for bytesoftype TT is compiled for (and, times four SIMDs, the workgroups that stay resident per
 // CU).  bytesoftype 8: its four waves need 30 KB of LDS, so five workgroups are all a CU holds anyway -- saying so gives the
-// plane-group encoder 96 vector registers instead of 64 (double sine: 8.5 -> 8.2 ms per 8 GiB).
-#ifndef STENOS_FUSED_OCCUPANCY_T8
-#define STENOS_FUSED_OCCUPANCY_T8 5
-#endif
-constexpr uint32_t fused_occupancy(uint32_t TT) { return TT == 8 ? STENOS_FUSED_OCCUPANCY_T8 : FUSED_OCCUPANCY; }
-#ifndef STENOS_FUSED_TICKETS
-#define STENOS_FUSED_TICKETS 0
-#endif
-#ifndef STENOS_FUSED_SPECULATE
-#define STENOS_FUSED_SPECULATE 1
-#endif
-constexpr bool FUSED_SPECULATE = STENOS_FUSED_SPECULATE != 0; // raw bytes of measured superblocks go straight to where a copy behind copies stands
-constexpr uint32_t FUSED_TICKETS = STENOS_FUSED_TICKETS; // superblocks per encoder workgroup; 0: as many as it gets (a resident grid) // waves per SIMD the register allocation of the fused kernel aims at
+// encoder 96 vector registers instead of 64 (double sine: 8.5 -> 8.2 ms per 8 GiB).
+constexpr uint32_t fused_occupancy(uint32_t TT) { return TT == 8 ? 5u : 8u; }
+constexpr bool FUSED_SPECULATE = true; // raw bytes of measured superblocks go straight to where a copy behind copies stands
 
 __device__ inline void chain_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint64_t chain_get(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -199,10 +185,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_
 	bool guess_copy = false; // the workgroup's last superblock ended up as a copy
 	if (threadIdx.x == 0)
 		shared[2] = 0;
-	for (uint32_t it = 0; FUSED_TICKETS == 0 || it <= FUSED_TICKETS; ++it) {
+	for (uint32_t it = 0;; ++it) {
 		const uint32_t parity = it & 1u;
 		if (threadIdx.x == 0)
-			shared[parity] = FUSED_TICKETS && it == FUSED_TICKETS ? 0xFFFFFFFFu : atomicAdd(ticket, 1u);
+			shared[parity] = atomicAdd(ticket, 1u);
 		__syncthreads();
 		if (shared[2]) // a wavefront of this workgroup gave up waiting: all leave together (the error is in j.status)
 			return;
@@ -219,11 +205,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_
 			const uint8_t* from = j.src + (s * j.bps + b0) * (uint64_t)(256 * T);
 			uint8_t* to = stage_w + (uint64_t)parity * FUSED_WAVES * run_cap;
 			for (uint32_t attempt = 0;; ++attempt) {
-#ifdef STENOS_EXP_MEASURE_ONLY // (timing experiment, no frames: loads, analysis and placement only)
-				const bool measure = true;
-#else
 				const bool measure = guess_copy && attempt == 0;
-#endif
 				// Speculative copy.  A superblock that is only measured is expected to be stored as a copy, and if every superblock
 				// before it is one too its place in the frame is known: header + s * (superblock + 4).  Its raw bytes go there
 				// while they pass through the registers of the measuring pass; when the offset arrives and is that place, the copy
@@ -242,11 +224,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_
 					run_size[k] = (uint32_t)__builtin_amdgcn_readfirstlane(runs[k]);
 				uint32_t code;
 				const uint32_t bytes = fused_superblock_size(j, run_size, &code);
-#ifndef STENOS_EXP_MEASURE_ONLY
 				if (measure && code != 6) { // it does compress: once more, with the bytes
-#else
-				if (false) {
-#endif
 					__syncthreads(); // (everyone has read the sizes before they are written again)
 					continue;
 				}
@@ -263,22 +241,9 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_
 			const uint64_t off = chain_wait(j, prev);
 			if (off == CHAIN_FAILED)
 				shared[2] = 1;
-#ifdef STENOS_EXP_DIRECT // (timing experiment, wrong frames: the run's bytes are written -- not copied -- to their place in the frame)
-			else {
-				uint32_t before = 0;
-				for (uint32_t k = 0; k < w; ++k)
-					before += prev_run[k];
-				uint8_t* to = j.dst + ((off + 4 + before + 15) & ~15ull);
-				const uint32_t groups = prev_run[w] >> 4;
-				for (uint32_t o = 0; o < groups; o += 64)
-					if (o + (threadIdx.x & 63u) < groups)
-						*(uint4*)(to + (o + (threadIdx.x & 63u)) * 16u) = make_uint4(o, w, groups, 1u);
-			}
-#elif !defined(STENOS_EXP_NO_STORE) // (timing experiment, wrong frames: what the staging read and the frame write cost)
 			else
 				fused_store(j, prev, w, off, prev_run, stage_w + (uint64_t)(parity ^ 1u) * FUSED_WAVES * run_cap,
 					    prev_spec && off == j.header_bytes + prev * (uint64_t)(j.sb_bytes + 4));
-#endif
 		}
 		if (!work)
 			return;
@@ -430,8 +395,6 @@ bool stenos_k_fused_supported(uint32_t T) { return T <= STENOS_K_LDS_MAX_T && FU
 // encoder workgroups of the fused kernel: as many as stay resident (they take superblocks until none is left)
 uint32_t stenos_k_fused_groups(uint64_t nsb, uint32_t T)
 {
-	if (FUSED_TICKETS)
-		return (uint32_t)((nsb + FUSED_TICKETS - 1) / FUSED_TICKETS);
 	const uint64_t resident = (uint64_t)stenos_k_cu_count() * (fused_occupancy(T) * 4 / FUSED_WAVES); // waves per SIMD x four SIMDs
 	return (uint32_t)(nsb < resident ? nsb : resident);
 }

@@ -239,10 +239,7 @@ WV_FN void resolve_capacity(Lds lds, const Layout& L, const FrameJob& j)
 // contiguous staging stream (encode_run), the workgroup learns the superblock's frame offset (sb_off[s], written
 // by the scanner wavefront of kernels.hip) and every wave copies its own run to its place in the frame.  No
 // per-block table and no separate pack pass.
-#ifndef STENOS_FUSED_WAVES
-#define STENOS_FUSED_WAVES 4
-#endif
-constexpr uint32_t FUSED_WAVES = STENOS_FUSED_WAVES;
+constexpr uint32_t FUSED_WAVES = 4;
 WV_HD uint32_t fused_run_blocks(uint32_t bps) { return (bps + FUSED_WAVES - 1) / FUSED_WAVES; }
 WV_HD uint32_t fused_run_capacity(uint32_t bps, uint32_t T) { return align16(fused_run_blocks(bps) * max_block_bytes(T)) + 64; }
 

@@ -143,7 +143,6 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 	const uint32_t r = rs.pos & 15u;
 	const uint32_t groups = (r + n) >> 4;
 	uint8_t* g = rs.base + (rs.pos - r);
-#ifndef STENOS_EXP_DIRECT // (timing experiment, wrong frames: nothing is staged; kernels.hip writes bytes of the right size at the right place)
 	{ // the first 64 groups without a loop around them: that is all of them unless the blocks hardly compress
 		Pred p = lane < U32(groups);
 		gst128(g, lane * 16u, lds_ld128(lds, U32(out) + sel(p, lane, U32(0u)) * 16u), p);
@@ -153,9 +152,6 @@ WV_FN void stream_append(RunStream& rs, Lds lds, uint32_t out, uint32_t n)
 		Pred p = k < U32(groups);
 		gst128(g, k * 16u, lds_ld128(lds, U32(out) + sel(p, k, U32(0u)) * 16u), p);
 	}
-#else
-	(void)g;
-#endif
 	// the group behind them (its bytes past the encoding are zero) waits in front of the image
 	Pred t = lane < U32(4u);
 	U32 a = sel(t, lane, U32(0u)) * 4u;
@@ -344,27 +340,6 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 				wide_ahead = 0;
 				WV_MARK("block_begin");
-#if defined(STENOS_PAD_CHEAP) || defined(STENOS_PAD_OTHER) || defined(STENOS_PAD_SALU)
-				{ // timing experiments only (tools/build_variant.sh): what an instruction of each class costs at the margin
-					uint32_t padv = 1, pads = 1;
-#ifdef STENOS_PAD_CHEAP
-#pragma unroll
-					for (int q = 0; q < STENOS_PAD_CHEAP; ++q)
-						asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(padv));
-#endif
-#ifdef STENOS_PAD_OTHER
-#pragma unroll
-					for (int q = 0; q < STENOS_PAD_OTHER; ++q)
-						asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(padv));
-#endif
-#ifdef STENOS_PAD_SALU
-#pragma unroll
-					for (int q = 0; q < STENOS_PAD_SALU; ++q)
-						asm volatile("s_add_u32 %0, %0, 1" : "+s"(pads) : : "scc");
-#endif
-					asm volatile("" : : "v"(padv), "s"(pads));
-				}
-#endif
 				const Layout M = sink.at(L);
 				SlotBatch B;
 				uint32_t keys0 = 0, keys1 = 0; // distinct hash keys among the first 40 values of each block (first rejection test of the mini-LZ)
@@ -651,13 +626,7 @@ WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* s
 // serve unaligned global accesses in hardware, so no lane reads a byte outside [src, src + n) and nothing has to be
 // shifted together from two aligned groups.  COPY_ROUNDS rounds of 64 groups at a time: all their loads are requested
 // before the first store, so the rounds cost one memory round trip.
-#ifndef STENOS_COPY_ROUNDS
-#define STENOS_COPY_ROUNDS 4
-#endif
-constexpr uint32_t COPY_ROUNDS = STENOS_COPY_ROUNDS;
-#ifndef STENOS_DECODE_COPY_ROUNDS
-#define STENOS_DECODE_COPY_ROUNDS 4
-#endif
+constexpr uint32_t COPY_ROUNDS = 4;
 #ifdef WV_PREDICATE_BRANCHES
 template <uint32_t ROUNDS = COPY_ROUNDS>
 WV_FN void copy_g2g_wide(uint8_t* dst, const uint8_t* src, uint32_t n)

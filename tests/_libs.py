@@ -100,6 +100,18 @@ def load_ref(det: bool = True):
         return None
 
 
+def load_hooks_library():
+    """The library the test suite builds for itself with its switches compiled in (tests/hooks/Makefile, -DSTENOS_TEST_HOOKS):
+    stenos_hip_test_lanes / _walk / _fused_timeouts exist there and nowhere else."""
+    from stenos_amd.api import load_library
+
+    d = os.path.join(ROOT, "tests", "hooks")
+    subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    lib = load_library(os.path.join(d, "libstenos_hooks.so"))
+    assert lib._stenos_test_hooks
+    return lib
+
+
 def np_ptr(a: np.ndarray) -> int:
     return a.ctypes.data
 

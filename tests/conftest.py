@@ -9,6 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+@pytest.fixture(scope="session")
+def hooks_lib():
+    """libstenos with the test switches compiled in (tests/hooks): only the tests that need a switch use it"""
+    from _libs import load_hooks_library
+
+    return load_hooks_library()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -24,14 +24,44 @@ def lib():
     return load_library()
 
 
-def test_every_declared_symbol_is_exported(lib):
-    declared = set()
+def _declared(text):
+    return set(re.findall(r"STENOS_EXPORT[^;(]*?\b(stenos_\w+)\s*\(", text))
+
+
+def _exported(path):
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_every_declared_symbol_is_exported_and_nothing_else(lib):
+    """libstenos.so exports exactly what include/*.h declares outside the test-only block: every name is stenos_*, none of the
+    C++ runtime's weak template instances or kernel host stubs leaks (csrc/libstenos.map), and the test suite's switches
+    (stenos_hip.h, #ifdef STENOS_TEST_HOOKS) are neither declared for a normal build nor exported."""
+    declared, hooks = set(), set()
     for h in ("stenos.h", "stenos_hip.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
-        declared |= set(re.findall(r"STENOS_EXPORT[^;(]*?\b(stenos_\w+)\s*\(", text))
-    assert len(declared) >= 30
+        m = re.search(r"#ifdef STENOS_TEST_HOOKS(.*?)#endif", text, re.S)
+        if m:
+            hooks |= _declared(m.group(1))
+            text = text.replace(m.group(0), "")
+        declared |= _declared(text)
+    assert len(declared) >= 30 and hooks == {"stenos_hip_test_lanes", "stenos_hip_test_walk", "stenos_hip_test_fused_timeouts"}
     for name in sorted(declared):
         assert hasattr(lib, name), name
+    exported = _exported(os.path.join(ROOT, "stenos_amd", "lib", "libstenos.so"))
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
+
+
+def test_the_test_build_has_the_switches():
+    """tests/hooks/libstenos_hooks.so: the same sources with -DSTENOS_TEST_HOOKS -- the product's exports plus the three switches."""
+    from _libs import load_hooks_library
+
+    load_hooks_library()
+    exported = _exported(os.path.join(ROOT, "tests", "hooks", "libstenos_hooks.so"))
+    product = _exported(os.path.join(ROOT, "stenos_amd", "lib", "libstenos.so"))
+    assert exported - product == {"stenos_hip_test_lanes", "stenos_hip_test_walk", "stenos_hip_test_fused_timeouts"} and product <= exported
 
 
 def test_bound_matches_reference_formula(lib, oracle):

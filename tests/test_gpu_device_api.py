@@ -135,26 +135,27 @@ def test_async_compress_then_finish(st):
     assert torch.equal(back, src)
 
 
-def test_fused_launch_that_gives_up_is_redone_without_the_fused_kernel():
+def test_fused_launch_that_gives_up_is_redone_without_the_fused_kernel(hooks_lib):
     """The fused encoder bounds its waits for frame offsets; a launch that gives up (injected here: it has never been
     observed) must end in the same frame, produced by encode_blocks / plan / scan / pack, not in an error."""
     import torch
 
     for kind, T, n in (("rand12", 4, 3_000_003), ("walk", 2, 2_000_001), ("sine", 8, 700_001)):
         src = generate_torch(kind, T, n, 5)
-        s = Stenos(level=1)
+        s = Stenos(level=1, lib=hooks_lib)
         dst = torch.zeros(s.bound(src.numel()), dtype=torch.uint8, device="cuda")
         want = s.compress(src, T, dst)
         ref = dst[:want].clone()
-        assert s.lib.stenos_hip_fused_fallbacks(s.ctx, 2) == 0
+        assert s.lib.stenos_hip_fused_fallbacks(s.ctx) == 0
+        s.lib.stenos_hip_test_fused_timeouts(s.ctx, 2)
         for wait in (True, False):
             dst.zero_()
             got = s.compress(src, T, dst) if wait else (s.compress(src, T, dst, wait=False), s.finish())[1]
             assert got == want and torch.equal(dst[:got], ref)
-        assert s.lib.stenos_hip_fused_fallbacks(s.ctx, 0) == 2
+        assert s.lib.stenos_hip_fused_fallbacks(s.ctx) == 2
         dst.zero_()
         assert s.compress(src, T, dst) == want and torch.equal(dst[:want], ref)  # and the fused kernel again afterwards
-        assert s.lib.stenos_hip_fused_fallbacks(s.ctx, 0) == 2
+        assert s.lib.stenos_hip_fused_fallbacks(s.ctx) == 2
         back = torch.zeros_like(src)
         assert s.decompress(dst, T, want, back) == src.numel() and torch.equal(back, src)
         s.close()

@@ -14,10 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def lib():
-    from stenos_amd.api import load_library
-
-    return load_library()
+def lib(hooks_lib):
+    return hooks_lib  # (stenos_hip_test_lanes: the test suite's own build, tests/hooks)
 
 
 def _context(lib, threads, level=1, opt_in=True, fail_lane=-1):

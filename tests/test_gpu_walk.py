@@ -24,10 +24,10 @@ def _index(st, frame, T, csize, serial):
 
 
 @pytest.mark.parametrize("kind,T,mib", [("rand12", 4, 300), ("rand", 4, 64), ("sorted_i32", 4, 512), ("sorted_i32", 4, 3000), ("walk", 2, 200), ("sine", 8, 100), ("sine", 4, 90), ("rand8", 2, 33)])
-def test_parallel_walk_equals_serial_walk_and_encoder_index(kind, T, mib):
+def test_parallel_walk_equals_serial_walk_and_encoder_index(kind, T, mib, hooks_lib):
     n = (mib << 20) // T + 4321
     src = generate_torch(kind, T, n, 17)
-    st = Stenos(1)
+    st = Stenos(1, lib=hooks_lib)
     dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device="cuda")
     c = st.compress(src, T, dst)
     p, nsb = st.last_index()
@@ -49,10 +49,10 @@ def test_parallel_walk_equals_serial_walk_and_encoder_index(kind, T, mib):
     st.close()
 
 
-def test_cut_and_padded_frames_agree_with_the_serial_walk():
+def test_cut_and_padded_frames_agree_with_the_serial_walk(hooks_lib):
     T = 4
     src = generate_torch("rand12", T, (96 << 20) // T + 99, 3)
-    st = Stenos(1)
+    st = Stenos(1, lib=hooks_lib)
     dst = torch.full((st.bound(src.numel()) + 70000,), 0x11, dtype=torch.uint8, device="cuda")
     c = st.compress(src, T, dst)
     rng = np.random.default_rng(1)
@@ -76,12 +76,12 @@ def test_cut_and_padded_frames_agree_with_the_serial_walk():
     st.close()
 
 
-def test_walk_time_is_small_next_to_the_decode():
+def test_walk_time_is_small_next_to_the_decode(hooks_lib):
     """8 GiB-class frames have tens of thousands of superblocks: one lane needs 0.35 us for each; the parallel walk must
     stay well below the decode kernel's time (2.4 ms per 8 GiB of int32)."""
     T = 4
     src = generate_torch("rand12", T, (2 << 30) // T, 42)
-    st = Stenos(1)
+    st = Stenos(1, lib=hooks_lib)
     dst = torch.empty(st.bound(src.numel()), dtype=torch.uint8, device="cuda")
     c = st.compress(src, T, dst)
     times = {}
