@@ -1215,6 +1215,23 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		// made of run-length rows, whose time is the mini-LZ's)
 		uint64_t todo = ballot(isr) & 0x1111111111111111ull; // one bit per row: that of its first lane
 		U32 extra(0u), total(0u);
+		if (todo == 0x1111111111111111ull) {
+			// Every row of the plane is a run-length row (long runs, steps, piecewise linear data: whole frames are made of such
+			// planes).  Sixteen fixed steps then, each the same in all lanes: the position of the row's mask, the mask, its size --
+			// no lane reads, no search for the next row, no loop control; a row's lanes keep what the step of their row found.
+			// (rowoff is the same in all lanes here: no row before has a payload of known size.)
+			todo = 0;
+			U32 at = rowoff, mine = rowoff;
+			for (uint32_t r = 0; r < 16; ++r) {
+				const U32 mk = lds_ld8(win, at) | (lds_ld8(win, at + 1u) << 8);
+				const Pred here = row == U32(r);
+				rmask = sel(here, mk, rmask);
+				mine = sel(here, at, mine);
+				at = at + (U32(18u) - popc(mk));
+			}
+			total = at - rowoff;
+			extra = mine - rowoff;
+		}
 		while (todo) {
 			const uint32_t rl = (uint32_t)__builtin_ctzll(todo);
 			todo &= todo - 1;

@@ -977,7 +977,7 @@ size_t compress_strategy(stenos_context_s* ctx, const uint8_t* h_src, const uint
 	// The block streams come to the host batch by batch on a stream of their own, in the order the batches are compressed:
 	// the transfer of batch k + 1 runs while batch k is in zstd (the link moves 50 GB/s, sixteen cores' zstd a quarter of
 	// that), and so does the upload of the finished part of the frame when the destination is device memory.
-	const size_t ample = 4 + f.sb + f.sb / 128 + 1024;
+	const size_t ample = (4 + f.sb + f.sb / 128 + 1024 + 15) & ~(size_t)15; // (a multiple of 16: the gather kernel reads the slots with aligned 16-byte loads)
 	uint64_t batch = ((size_t)256 << 20) / f.sb;
 	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
 	const uint64_t nbatch = (f.nsb + batch - 1) / batch;

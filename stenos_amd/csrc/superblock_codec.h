@@ -183,9 +183,9 @@ struct StreamSink { // a contiguous stream in HBM (RunStream)
 	bool writes; // false: sizes only, nothing is written (a superblock that is expected to end up as a copy, kernels.hip)
 	// A superblock that is only measured because it will probably be stored as a copy: where its raw bytes would go in that
 	// case (kernels.hip, speculative copy); the blocks are stored there from the registers they were loaded into anyway.
-	// nullptr: nowhere.  raw_ok turns false when a block went another way (the general encoder: not stored).
+	// nullptr: nowhere.  Every path of encode_blocks_to stores the blocks it takes (the row-lane passes and groups from the
+	// registers they loaded them into, the plane-group loop from its LDS copy): kernels.hip relies on that when it skips the copy.
 	uint8_t* raw_to = nullptr;
-	bool raw_ok = true;
 	WV_MFN void raw8(const RawBlock8& b, uint32_t block)
 	{
 		gst128_through(raw_to + (uint64_t)block * 2048u, lane_id() * 32u, b.a);
@@ -735,6 +735,15 @@ WV_HD uint32_t window_bytes(uint32_t T) { return align16(max_tail_bytes(T) + 204
 // the window reads at most hs + T*(8 + 18 + 16*18) + 16 bytes from there whatever the stream contains, so that much LDS
 // has to follow the window's buffer (the image and some padding behind it; stale bytes are harmless).
 WV_HD uint32_t max_block_reach(uint32_t T) { return header_bytes(T) + T * 314 + 32; }
+// lz_decode_256 (block_codec.h) packs a group's window offset into 16 bits and keeps a 256-byte table behind the image's
+// first 256 * T bytes, in the slack make_dec_layout leaves there: both hold for the element sizes that use it (4 and 8), and
+// a change to the window or to the reach of a block that broke them would fail here, not corrupt a table.
+static_assert(256 * 4 + 32 <= 65535 && 256 * 8 + 32 <= 65535, "");
+WV_HD constexpr uint32_t dec_image_slack(uint32_t T) // bytes between the decoded block (256 * T) and the tables behind the image
+{
+	return ((256 * T + 32 > ((T + 1) / 2 + T * 314 + 32) ? 256 * T + 32 : ((T + 1) / 2 + T * 314 + 32)) + 15) / 16 * 16 - 256 * T;
+}
+static_assert(dec_image_slack(4) >= 256 && dec_image_slack(8) >= 256, "lz_decode_256 keeps a 256-byte table behind the decoded block");
 WV_HD DecLayout make_dec_layout(uint32_t T)
 {
 	DecLayout L;

@@ -12,7 +12,7 @@ import pytest
 from _libs import ROOT, has_error, np_ptr
 from stenos_amd.datagen import generate
 
-KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst", "mixed", "lzmix", "edge_noise"]
+KINDS = ["rand", "same", "sorted", "walk", "ramp", "dict16", "runs", "burst", "mixed", "lzmix", "edge_noise", "steps", "slopes"]
 
 
 @pytest.fixture(scope="module", params=["libstenos_emul.so", "libstenos_emul_enc.so"], ids=["decode-shapes", "encode-shapes"])

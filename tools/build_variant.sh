@@ -1,5 +1,6 @@
 #!/bin/bash
-# An experimental build of the library with extra compiler flags: stenos_amd/lib/exp/libstenos_<name>.so (git-ignored, travels
+# An experimental build of the library with extra compiler flags (the product sources hold no experiment switch any more -- tests/test_build_properties.py --: a
+# variant is a patch to the sources plus, maybe, generic flags such as -mllvm options): stenos_amd/lib/exp/libstenos_<name>.so (git-ignored, travels
 # to the GPU box; tools/exp_variants.sh and STENOS_LIB_PATH select it).  usage: tools/build_variant.sh <name> [-DSTENOS_...=.. ...]
 set -e
 name="$1"; shift
