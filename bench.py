@@ -265,7 +265,7 @@ def measure_other(name, torch, dist, dev, with_cpu):
 # Counters cannot be collected inside a bench run: the HBM traffic of a configuration is the figure of the committed profile
 # of the same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_config.sh + tools/pmc_summary.py,
 # with the FETCH x 2 correction of the guide), quoted with its origin.
-TRAFFIC_PROFILES = {"int32": "pmc_traffic.json", "int32_rand": "r04_pmc_int32_rand.json", "int16": "r04_pmc_int16.json", "double": "r04_pmc_double.json"}
+TRAFFIC_PROFILES = {"int32": "pmc_traffic.json", "int32_rand": "r05_pmc_int32_rand.json", "int16": "r05_pmc_int16.json", "double": "r05_pmc_double.json"}
 
 
 def profiled_traffic(key, kernel="encode_superblocks"):

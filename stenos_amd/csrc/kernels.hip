@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_
 	bool prev_spec = false;       // ... and its raw bytes were put where a copy behind copies goes
 	uint32_t prev_run[FUSED_WAVES];
 	bool guess_copy = false; // the workgroup's last superblock ended up as a copy
+	bool group_hint = true;  // the wave's last blocks had the shape that groups of four blocks want (superblock_codec.h)
 	if (threadIdx.x == 0)
 		shared[2] = 0;
 	for (uint32_t it = 0;; ++it) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, fused_occupancy(TT)) void encode_
 				// those bytes writes them later -- later superblocks learn their offsets only after this one has published its
 				// size, which it does after its stores -- write-through: the XCDs' L2s are not coherent -- have completed.
 				uint8_t* const spec_to = measure && FUSED_SPECULATE ? j.dst + j.header_bytes + s * (uint64_t)(j.sb_bytes + 4) + 4 + (uint64_t)b0 * (256 * T) : nullptr;
-				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to, true, NoPassHook(), spec_to);
+				const uint32_t n = encode_run(g_lds + w * L.total, L, T, from, b1 - b0, measure ? nullptr : to, true, NoPassHook(), spec_to, &group_hint);
 				if (spec_to)
 					gst_through_wait(); // (write-through stores: in memory before the size is published)
 				if ((threadIdx.x & 63u) == 0)

@@ -186,6 +186,9 @@ struct StreamSink { // a contiguous stream in HBM (RunStream)
 	// nullptr: nowhere.  Every path of encode_blocks_to stores the blocks it takes (the row-lane passes and groups from the
 	// registers they loaded them into, the plane-group loop from its LDS copy): kernels.hip relies on that when it skips the copy.
 	uint8_t* raw_to = nullptr;
+	// Whether the last blocks the wave saw had the shape that groups of four want (encode_blocks_to): kept by the caller from
+	// run to run, so that a run of noise does not begin with four loads for nothing.  nullptr: every run tries once.
+	bool* group_hint = nullptr;
 	WV_MFN void raw8(const RawBlock8& b, uint32_t block)
 	{
 		gst128_through(raw_to + (uint64_t)block * 2048u, lane_id() * 32u, b.a);
@@ -214,6 +217,20 @@ struct StreamSink { // a contiguous stream in HBM (RunStream)
 // tight buffer.
 // slots: bytesoftype 2 and 4 go through the plane slots (slot_codec.h, up to two blocks per pass); false: the plane-group
 // loop at the bottom.
+// When to try the noise proof of a pass (slot_codec.h, slot_rows_analyse): a failed attempt costs a dozen vector instructions
+// that a pass of coded planes pays for nothing, so after one the next seven passes of that position go without, then one tries
+// again (data changes character seldom, and a pass of noise that is not tried is merely analysed in full).
+struct RawProofHint {
+	uint32_t wait = 0;
+	WV_MFN bool want()
+	{
+		if (wait == 0)
+			return true;
+		--wait;
+		return false;
+	}
+	WV_MFN void tried(bool all_raw) { wait = all_raw ? 0u : 7u; }
+};
 struct NoPassHook {
 	WV_MFN void operator()() const {}
 };
@@ -234,7 +251,8 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 		// Four blocks with the same two planes that are not constant, taken plane by plane (slot_codec.h, "groups of four
 		// blocks").  False: the blocks are not of that shape, or one of them may go to the mini-LZ -- nothing has been written,
 		// the pass below takes them.  try_group: the last blocks seen had the shape (or nothing is known yet).
-		bool try_group = true;
+		bool try_group = sink.group_hint ? *sink.group_hint : true;
+		RawProofHint proof0, proof1; // (the first and the second pass of a group; the passes below use the first)
 		auto group4 = [&]() __attribute__((always_inline)) -> bool {
 			const uint8_t* a = src + (uint64_t)i * bs;
 			WV_MARK("g4_load");
@@ -275,11 +293,17 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			wave_sync();
 			SlotRows R;
 			WV_MARK("g4_pass0");
-			const bool raw0 = slot_rows_analyse(lds, M, R, 0, 4);
+			const bool try0 = proof0.want();
+			const bool raw0 = slot_rows_analyse(lds, M, R, 0, 4, try0);
+			if (try0)
+				proof0.tried(raw0);
 			const U32 ts0 = R.ts, hm0 = R.hm, pm0 = R.pm;
 			const Pred emitmin0 = R.emitmin, eq0 = R.eq;
 			WV_MARK("g4_pass1");
-			slot_rows_analyse(lds, M, R, 1024, 4);
+			const bool try1 = proof1.want();
+			const bool raw1 = slot_rows_analyse(lds, M, R, 1024, 4, try1);
+			if (try1)
+				proof1.tried(raw1);
 			WV_MARK("g4_sizes");
 			const U32 bsz = (ts0 & 0xFFFFu) + R.size() + U32(hs + T - 2u); // the block of the lane's slot
 			U32 incl = bsz + scan_source(bsz, 4, 0u);
@@ -417,7 +441,12 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				if (W.nblk) {
 					SlotRows R;
 					if (W.nslots)
-						slot_rows_analyse(lds, M, R, 0, W.nslots);
+					{
+						const bool tryw = proof0.want();
+						const bool raww = slot_rows_analyse(lds, M, R, 0, W.nslots, tryw);
+						if (tryw)
+							proof0.tried(raww);
+					}
 					else {
 						for (int k = 0; k < 4; ++k)
 							R.sb[k] = R.sd[k] = U32(0u);
@@ -439,7 +468,12 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				}
 				SlotRows R;
 				if (B.nslots)
-					slot_rows_analyse(lds, M, R, 0, B.nslots);
+				{
+					const bool tryb = proof0.want();
+					const bool rawb = slot_rows_analyse(lds, M, R, 0, B.nslots, tryb);
+					if (tryb)
+						proof0.tried(rawb);
+				}
 				else { // only constant planes: nothing to measure
 					for (int k = 0; k < 4; ++k)
 						R.sb[k] = R.sd[k] = U32(0u);
@@ -514,11 +548,14 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 		}
 		if (i < nblocks)
 			pass(std::false_type());
+		if (sink.group_hint)
+			*sink.group_hint = try_group;
 		return;
 	}
 	if (slots && T == 8) {
 		// bytesoftype 8 (slot_codec.h): one block per batch, its non-constant planes in one or two passes of four slots.
 		const uint32_t bs = 2048, hs = header_bytes(8);
+		RawProofHint proof0, proof1; // (the block's first and second pass)
 		// (requesting the next block as soon as the current one has left its registers for the slots was measured: +1 % on double
 		// sine -- the eight registers it holds across the passes cost more than the wait it removes)
 		for (uint32_t i = 0; i < nblocks; ++i) {
@@ -548,13 +585,19 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			if (n0) {
 				write_slots8(lds, M, eb, mask0);
 				wave_sync();
-				slot_rows_analyse(lds, M, R0, 0, n0);
+				const bool try0 = proof0.want();
+				const bool raw0 = slot_rows_analyse(lds, M, R0, 0, n0, try0);
+				if (try0)
+					proof0.tried(raw0);
 				incl0 = slot_pass_sizes(R0, n0, &pt0);
 			}
 			if (n1) {
 				write_slots8(lds, M, eb, mask1);
 				wave_sync();
-				slot_rows_analyse(lds, M, R1, 0, n1);
+				const bool try1 = proof1.want();
+				const bool raw1 = slot_rows_analyse(lds, M, R1, 0, n1, try1);
+				if (try1)
+					proof1.tried(raw1);
 				incl1 = slot_pass_sizes(R1, n1, &pt1);
 			}
 			const uint32_t full = pt0 + pt1 + (8 - sc.nact);
@@ -607,9 +650,10 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 // raw_to (only without a stage): the blocks' raw bytes are stored there on the way (StreamSink::raw_to)
 template <class Hook = NoPassHook>
 WV_FN uint32_t encode_run(Lds lds, const Layout& L, uint32_t T, const uint8_t* src, uint32_t nblocks, uint8_t* stage, bool slots = true, Hook hook = Hook(),
-			  uint8_t* raw_to = nullptr)
+			  uint8_t* raw_to = nullptr, bool* group_hint = nullptr)
 {
 	StreamSink sink;
+	sink.group_hint = group_hint;
 	sink.rs.base = stage;
 	sink.rs.pos = 0;
 	sink.writes = stage != nullptr;
