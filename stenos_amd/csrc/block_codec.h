@@ -41,6 +41,7 @@ struct Layout {
 	uint32_t rowinfo; // T*16 entries of 8 bytes
 	uint32_t plinfo;  // T entries of 4 bytes
 	uint32_t rlelut;  // row lanes (bytesoftype 2, 4, 8): the 16 v_perm_b32 selectors that compact the literals of a run-length group, written once per run
+	uint32_t grp;     // bytesoftype 2, 4: three tables of eight words for a group of blocks (slot_codec.h, "groups of any shape")
 	uint32_t aux;     // 64 entries of 8 bytes: row statistics of the current plane group (dead once the planes are analysed)
 	uint32_t lz;      // mini-LZ chain count*4 + cur count*4, on top of aux; its 256-entry table uses the not yet written image
 	uint32_t skip;    // mini-LZ: one bit per group that was left raw (32 bytes up to bytesoftype 64)
@@ -80,6 +81,8 @@ WV_HD Layout make_layout(uint32_t T, bool with_lz)
 	o += align16(T * 4);
 	L.rlelut = o; // (64 bytes; slot_codec.h)
 	o += (T == 2 || T == 4 || T == 8) ? 64 : 0;
+	L.grp = o; // (96 bytes: first elements, plane sizes and types, plane positions)
+	o += (T == 2 || T == 4) ? 96 : 0;
 	L.skip = o;
 	o += lz_skip_bytes(T);
 	L.aux = o;

@@ -695,6 +695,101 @@ WV_FN void group4_emit_heads(Lds lds, const Layout& L, uint32_t T, uint32_t k0, 
 	put_small(out, sel(nib, bbase * 8u + plane * 4u, where * 8u), sel(nib, type, byte), r < U32(T), own);
 }
 
+// ---- groups of any shape (bytesoftype 2 and 4) -----------------------------------------------------------------------------
+// Consecutive blocks -- up to eight of 16-bit elements, four of 32-bit ones: sixteen registers of raw elements either way --
+// whose planes that are not constant number eight at most are taken together whatever their shapes: the planes go into the eight
+// slots in PLANE-MAJOR order (plane 0 of every block that has one, then plane 1, ...), so planes of one kind still share a pass
+// and every pass is as full as the data allows -- a random walk of 16-bit samples has one or two planes to code per block in no
+// fixed pattern, and pairs of its blocks filled three slots of four.  Which (block, plane) a slot holds is data here, not a
+// shape known in advance: sixteen "element lanes" -- lane l stands for plane l mod T of block l / T -- work out the slot of
+// their plane, fetch its size and type, add up the blocks and find where every plane and every constant byte goes; three tables
+// of eight words in LDS (Layout::grp) carry first elements, sizes and positions between them and the row lanes.
+constexpr uint32_t GRP_FIRST = 0, GRP_TS = 32, GRP_POS = 64; // offsets of the three tables inside Layout::grp
+
+// the planes of `act` of a block into the slots slot_of[0], slot_of[1], ... (in plane order)
+WV_FN void write_slots_at(Lds lds, const Layout& L, const RawBlock& b, uint32_t T, uint32_t act, const uint32_t* slot_of)
+{
+	const U32 a = U32(slot2_area(L)) + lane_id() * 4u;
+	uint32_t k = 0;
+	if (T == 2) {
+		if (act & 1u)
+			lds_st32(lds, a + slot_of[k++] * SLOT2_BYTES, perm_bytes(b.e.y, b.e.x, 0x06040200u), pred_all(true));
+		if (act & 2u)
+			lds_st32(lds, a + slot_of[k] * SLOT2_BYTES, perm_bytes(b.e.y, b.e.x, 0x07050301u), pred_all(true));
+		return;
+	}
+	if (act & 3u) {
+		const U32 t0 = perm_bytes(b.e.y, b.e.x, 0x05010400u), t2 = perm_bytes(b.e.w, b.e.z, 0x05010400u);
+		if (act & 1u)
+			lds_st32(lds, a + slot_of[k++] * SLOT2_BYTES, perm_bytes(t2, t0, 0x05040100u), pred_all(true));
+		if (act & 2u)
+			lds_st32(lds, a + slot_of[k++] * SLOT2_BYTES, perm_bytes(t2, t0, 0x07060302u), pred_all(true));
+	}
+	if (act & 12u) {
+		const U32 t1 = perm_bytes(b.e.y, b.e.x, 0x07030602u), t3 = perm_bytes(b.e.w, b.e.z, 0x07030602u);
+		if (act & 4u)
+			lds_st32(lds, a + slot_of[k++] * SLOT2_BYTES, perm_bytes(t3, t1, 0x05040100u), pred_all(true));
+		if (act & 8u)
+			lds_st32(lds, a + slot_of[k] * SLOT2_BYTES, perm_bytes(t3, t1, 0x07060302u), pred_all(true));
+	}
+}
+
+// What the element lanes of a group know once its passes are analysed (the sizes and types of the slots stand in the table
+// GRP_TS): lane l < nb * T stands for plane l % T of block l / T.
+struct GroupPlace {
+	U32 pos;      // where the lane's plane (or constant byte) goes, from the image's start
+	U32 ts;       // size | type << 16 of the lane's plane (1 | 0 for a constant one)
+	U32 bstart;   // start of the lane's block in the image
+	U32 bsize;    // size of the lane's block
+	Pred valid, active;
+	uint32_t total; // bytes of all blocks
+};
+// acts: bit l = plane l % T of block l / T is not constant; base: where the first block starts in the image
+WV_FN GroupPlace group_place(Lds lds, const Layout& L, uint32_t T, uint32_t nb, uint32_t acts, uint32_t base)
+{
+	GroupPlace G;
+	const U32 lane = lane_id();
+	const uint32_t lg = T == 2 ? 1u : 2u, hs = header_bytes(T);
+	const U32 j = lane & U32(T - 1u);
+	G.valid = lane < U32(nb * T);
+	G.active = G.valid & (((U32(acts) >> (lane & 31u)) & 1u) != U32(0u));
+	// the slot of the lane's plane in plane-major order: the planes of lower number of all blocks, then this plane of the blocks in front
+	const uint32_t every = T == 2 ? 0x5555u : 0x1111u; // plane 0 of every block
+	const U32 lower = U32(every) * ((U32(1u) << j) - 1u);  // planes of lower number
+	const U32 mine = U32(every) << j;
+	const U32 slot = popc(U32(acts) & lower) + popc(U32(acts) & mine & ((U32(1u) << (lane & 31u)) - 1u));
+	G.ts = sel(G.active, lds_ld32(lds, U32(L.grp + GRP_TS) + sel(G.active, slot, U32(0u)) * 4u), sel(G.valid, U32(1u), U32(0u)));
+	const U32 zz = G.ts & 0xFFFFu;
+	// inclusive sums inside the block's T lanes
+	U32 incl = zz + sel(j >= U32(1u), shfl_up(zz, 1, 0u), U32(0u));
+	if (T == 4)
+		incl = incl + sel(j >= U32(2u), shfl_up(incl, 2, 0u), U32(0u));
+	// the block's size in its last lane -> all of its lanes (a read from lane | (T - 1))
+	const U32 bsum = shfl(incl, lane | U32(T - 1u));
+	G.bsize = sel(G.valid, bsum + U32(hs), U32(0u));
+	const U32 upto = wave_incl_scan(sel(j == U32(0u), G.bsize, U32(0u))); // blocks up to and with the lane's
+	G.bstart = U32(base) + upto - G.bsize;
+	G.pos = G.bstart + U32(hs) + (incl - zz);
+	G.total = readlane(upto, 15);
+	(void)lg;
+	// the row lanes read where their slot's plane goes
+	lds_st32(lds, U32(L.grp + GRP_POS) + sel(G.active, slot, U32(0u)) * 4u, G.pos, G.active);
+	wave_sync();
+	return G;
+}
+// type nibbles and the bytes of the constant planes of all blocks of the group, by the element lanes
+WV_FN void group_emit_heads(Lds lds, const Layout& L, uint32_t T, const GroupPlace& G, uint32_t scr)
+{
+	const U32 lane = lane_id();
+	Lds out = lds + L.out;
+	const U32 own = U32(slot2_area(L) + scr - L.out) + lane * 16u;
+	const U32 j = lane & U32(T - 1u);
+	const U32 b = lane >> (T == 2 ? 1u : 2u);
+	put_small(out, G.bstart * 8u + j * 4u, G.ts >> 16, G.active, own); // (a constant plane's type is 0: nothing to write)
+	const U32 first = lds_ld32(lds, U32(L.grp + GRP_FIRST) + (b & 7u) * 4u);
+	put_small(out, G.pos * 8u, (first >> (j << 3)) & 0xFFu, G.valid & !G.active, own);
+}
+
 // ---- bytesoftype 8 -----------------------------------------------------------------------------------------------------
 // One block per batch: its non-constant planes take the four slots in plane order, the first four in one pass, the rest
 // (doubles and 64-bit integers seldom have fewer than five) in a second one.  Both passes are analysed before anything is

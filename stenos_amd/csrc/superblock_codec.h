@@ -17,6 +17,11 @@ inline uint64_t& emul_group4_count()
 	static uint64_t n = 0;
 	return n;
 }
+inline uint64_t& emul_group_any_count()
+{
+	static uint64_t n = 0;
+	return n;
+}
 #endif
 
 // ---- HBM <-> LDS copies by one wave ---------------------------------------------------------------
@@ -314,7 +319,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				const uint32_t f0 = readlane(bsz, 0) - hs, f1 = readlane(bsz, 16) - hs, f2 = readlane(bsz, 32) - hs, f3 = readlane(bsz, 48) - hs;
 				if ((f0 * 3 > bs && lz_precheck_passes(T, keys0, f0)) || (f1 * 3 > bs && lz_precheck_passes(T, keys1, f1)) ||
 				    (f2 * 3 > bs && lz_precheck_passes(T, keys2, f2)) || (f3 * 3 > bs && lz_precheck_passes(T, keys3, f3))) {
-					try_group = false;
+					try_group = false; // (the groups of any shape look at such blocks again; then the pass)
 					return false;
 				}
 			}
@@ -338,6 +343,144 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			++emul_group4_count(); // (tests/emul: the tests assert that the inputs meant for this path take it)
 #endif
 			i += 4;
+			hook();
+			return true;
+		};
+		// Blocks of any shapes whose planes that are not constant fill the eight slots, plane-major (slot_codec.h, "groups of any
+		// shape").  False: fewer than two blocks fit, or one of them may go to the mini-LZ -- nothing has been written, the pass
+		// below takes them.
+		bool try_any = true;
+		auto group_any = [&]() __attribute__((always_inline)) -> bool {
+			constexpr uint32_t NBMAX = 8;
+			const uint32_t NB = T == 2 ? 8u : 4u;
+			const uint32_t avail = nblocks - i < NB ? nblocks - i : NB;
+			const uint8_t* a = src + (uint64_t)i * bs;
+			WV_MARK("ga_load");
+			RawBlock e[NBMAX];
+#pragma unroll
+			for (uint32_t q = 0; q < NBMAX; ++q)
+				if (q < NB && q < avail)
+					e[q] = load_raw_block(a + (uint64_t)q * bs, T);
+			const Layout M = sink.at(L);
+			WV_MARK("ga_front");
+			// the blocks that fit: their masks packed T bits a block, their first elements in the table
+			uint32_t acts = 0, nb = 0, total = 0, keys[4] = { 0, 0, 0, 0 };
+			bool open = true;
+#pragma unroll
+			for (uint32_t q = 0; q < NBMAX; ++q)
+				if (q < NB && q < avail && open) {
+					const SameScan sq = scan_same_fast(e[q], T);
+					if (total + sq.nact <= 8) {
+						acts |= sq.act << (T * q);
+						total += sq.nact;
+						nb = q + 1;
+						lds_st32(lds, U32(M.grp + GRP_FIRST + 4 * q), U32(sq.first), lane_id() == U32(0u));
+						if (T == 4 && sq.nact >= 2)
+							keys[q & 3u] = lz_distinct_keys_fast<2>(lds, M, e[q].e);
+					}
+					else
+						open = false;
+				}
+			if (nb < 2) {
+				try_any = false;
+				return false;
+			}
+			// slots in plane-major order: the planes of lower number of all blocks, then this plane of the blocks in front
+			{
+				const uint32_t every = T == 2 ? 0x5555u : 0x1111u;
+#pragma unroll
+				for (uint32_t q = 0; q < NBMAX; ++q)
+					if (q < NB && q < nb) {
+						const uint32_t actq = (acts >> (T * q)) & ((1u << T) - 1u);
+						uint32_t slot_of[4] = { 0, 0, 0, 0 }, k = 0;
+						for (uint32_t jj = 0; jj < T; ++jj)
+							if ((actq >> jj) & 1u) {
+								const uint32_t lower = every * ((1u << jj) - 1u), mine = every << jj;
+								slot_of[k++] = (uint32_t)__builtin_popcount(acts & lower) + (uint32_t)__builtin_popcount(acts & mine & ((1u << (T * q + jj)) - 1u));
+							}
+						write_slots_at(lds, M, e[q], T, actq, slot_of);
+					}
+			}
+			if (sink.raw_to) { // (measured only, probably a copy: the raw bytes go where the copy would put them)
+#pragma unroll
+				for (uint32_t q = 0; q < NBMAX; ++q)
+					if (q < NB && q < nb)
+						sink.raw(e[q], T, i + q);
+			}
+			wave_sync();
+			const uint32_t n0 = total < 4 ? total : 4, n1 = total - n0;
+			SlotRows R;
+			U32 ts0(0u), hm0(0u), pm0(0u);
+			Pred emitmin0 = pred_all(false), eq0 = pred_all(false);
+			bool raw0 = false;
+			const U32 lane = lane_id();
+			if (n0) {
+				WV_MARK("ga_pass0");
+				const bool try0 = proof0.want();
+				raw0 = slot_rows_analyse(lds, M, R, 0, n0, try0);
+				if (try0)
+					proof0.tried(raw0);
+				lds_st32(lds, U32(M.grp + GRP_TS) + (lane >> 4) * 4u, R.ts, ((lane & 15u) == U32(0u)) & ((lane >> 4) < U32(n0)));
+			}
+			if (n1) {
+				ts0 = R.ts, hm0 = R.hm, pm0 = R.pm;
+				emitmin0 = R.emitmin, eq0 = R.eq;
+				WV_MARK("ga_pass1");
+				const bool try1 = proof1.want();
+				const bool raw1 = slot_rows_analyse(lds, M, R, 1024, n1, try1);
+				if (try1)
+					proof1.tried(raw1);
+				lds_st32(lds, U32(M.grp + GRP_TS + 16) + (lane >> 4) * 4u, R.ts, ((lane & 15u) == U32(0u)) & ((lane >> 4) < U32(n1)));
+			}
+			wave_sync();
+			WV_MARK("ga_place");
+			const GroupPlace G = group_place(lds, M, T, nb, acts, sink.base());
+			if (T == 4) {
+				// a block the mini-LZ may take (block_compress.h:1210-1221): the pass below decides and encodes it
+				bool cand = false;
+#pragma unroll
+				for (uint32_t q = 0; q < 4; ++q)
+					if (q < nb && !cand) {
+						const uint32_t f = readlane(G.bsize, 4 * q) - hs;
+						if (f * 3 > bs && lz_precheck_passes(T, keys[q], f)) {
+							// (the count over 40 values turns most blocks away; one it does not is looked at again, as in the pass below: the
+							// test that turns noise away, then the count over all 80 values)
+							const RawBlock again = load_raw_block(a + (uint64_t)q * bs, T);
+							cand = !lz_repeats_reject(lds, M, again.e, f) && lz_precheck_passes(T, lz_distinct_keys_fast<4>(lds, M, again.e), f);
+						}
+					}
+				if (cand) {
+					try_any = false;
+					return false;
+				}
+			}
+			if (sink.writes) {
+				WV_MARK("ga_emit");
+				image_reset_group4(lds, M);
+				group_emit_heads(lds, M, T, G, 1024);
+				// the rows of the pass that is in registers, then (two passes) the first one's, read again from their slots;
+				// the second KiB of the slot area is the scratch of both emissions
+				const U32 sl = lane >> 4;
+				if (n1) {
+					const U32 pb1 = lds_ld32(lds, U32(M.grp + GRP_POS + 16) + sl * 4u);
+					slot_rows_emit_rows(lds, M, R, sl < U32(n1), pb1, 1024);
+					slot_rows_reload(lds, M, R, 0, !raw0);
+					R.ts = ts0, R.hm = hm0, R.pm = pm0;
+					R.emitmin = emitmin0, R.eq = eq0;
+				}
+				if (n0) {
+					const U32 pb0 = lds_ld32(lds, U32(M.grp + GRP_POS) + sl * 4u);
+					slot_rows_emit_rows(lds, M, R, sl < U32(n0), pb0, 1024);
+				}
+			}
+			WV_MARK("ga_append");
+			sink.append(lds, M, G.total);
+			// (blocks of one shape with two planes each are the groups of four's: cheaper placement)
+			try_group = nb == 4 && total == 8 && ((acts ^ (acts >> T)) & ((1u << (3 * T)) - 1u)) == 0;
+#ifdef WV_HOST_EMULATION
+			++emul_group_any_count();
+#endif
+			i += nb;
 			hook();
 			return true;
 		};
@@ -396,6 +539,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				B.nblk = nblk;
 				// (the next four blocks probably look like these two: worth a try as a group, below)
 				try_group = nblk == 2 && B.act[0] == B.act[1] && B.nact0 == 2;
+				try_any = true;
 				// Two blocks with at most one non-constant plane each leave slots free: the blocks behind them move in while
 				// they have at most one such plane themselves (a wide batch, slot_codec.h).
 				SlotBatch4 W;
@@ -517,7 +661,7 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 					return;
 				}
 			}
-			try_group = false; // (blocks the mini-LZ may take are encoded one at a time)
+			try_group = try_any = false; // (blocks the mini-LZ may take are encoded one at a time)
 			// a mini-LZ attempt, one block at a time (the raw bytes of a measured superblock have been put in place already,
 			// above).  The candidates' sizes without the mini-LZ are known from the pass -- it left them in the plane table's
 			// place, so that nothing of this rare path is alive in the pass --: the attempt needs nothing else, and the general
@@ -542,6 +686,13 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 			if (try_group && i + 3 < nblocks) {
 				WV_NESTED();
 				if (group4())
+					continue;
+			}
+			// (bytesoftype 2 only: for 32-bit elements the blocks of one shape have their groups of four, and a third copy of the
+			// row-lane machinery in that kernel costs it 34 spilled registers -- measured: every int32 workload 10-25 % slower)
+			if (T == 2 && try_any) {
+				WV_NESTED();
+				if (group_any())
 					continue;
 			}
 			pass(std::true_type());

@@ -101,6 +101,7 @@ void emul_dec_layout(size_t T, uint32_t* out)
 }
 static size_t g_last_fused = 0;
 void emul_set_fused(int on) { g_fused = on; }
+size_t emul_group_any_count(void) { return (size_t)codec::emul_group_any_count(); } // groups of any shape encoded so far
 size_t emul_group4_count(void) { return (size_t)codec::emul_group4_count(); } // groups of four blocks encoded plane by plane so far (superblock_codec.h)
 size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last frame sent through the fused path
 

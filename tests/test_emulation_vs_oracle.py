@@ -212,6 +212,34 @@ def test_slot_rows_encoder_on_plane_mixtures(oracle, emul, T):
             assert r2 == r1 and np.array_equal(out[:r2], f1), (kind, seed)
 
 
+def test_groups_of_blocks_are_taken_where_they_are_meant_to(oracle, emul):
+    """The inputs the group paths of the fused encoder were made for go through them (superblock_codec.h): 12-bit integers in
+    32-bit elements in groups of four blocks (the same two planes in every block), a random walk of 16-bit samples -- one or
+    two planes to code per block, in no fixed pattern -- in groups of any shape; frames equal the oracle's either way."""
+    from _libs import oracle_compress
+
+    emul.emul_set_fused(1)
+    emul.emul_set_slots(1)
+    emul.emul_compress_frame.restype = c_size_t
+    emul.emul_compress_frame.argtypes = [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_int]
+    emul.emul_group4_count.restype = c_size_t
+    emul.emul_group_any_count.restype = c_size_t
+    for kind, T, want4, want_any in (("rand12", 4, True, False), ("walk", 2, False, True), ("mixed", 2, False, True), ("dict16", 4, False, False)):
+        per = 131072 // (256 * T) * 256
+        data = generate(kind, T, 3 * per + 333, 9)
+        blocks = data.nbytes // (256 * T)
+        cap = oracle.so_bound(data.nbytes) + 5000
+        r1, f1 = oracle_compress(oracle, data, T, 1, cap)
+        out = np.zeros(cap, dtype=np.uint8)
+        g4, ga = emul.emul_group4_count(), emul.emul_group_any_count()
+        r2 = emul.emul_compress_frame(np_ptr(data), T, data.nbytes, np_ptr(out), cap, 1)
+        g4, ga = emul.emul_group4_count() - g4, emul.emul_group_any_count() - ga
+        assert r2 == r1 and np.array_equal(out[:r2], f1), kind
+        assert (g4 * 4 >= blocks - 8) == want4, (kind, g4, blocks)
+        assert (ga > blocks // 16) == want_any, (kind, ga, blocks)
+
+
+
 @pytest.mark.parametrize("T", [2, 4, 8])
 def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T):
     """After a superblock that ended up as a copy the fused kernel only measures the next one and encodes it for real when
