@@ -254,6 +254,7 @@ struct stenos_context_s {
 	hipStream_t copy_stream = nullptr, upload_stream = nullptr; // levels >= 2: block streams to the host / the frame to the device, beside the host's zstd
 	std::vector<hipEvent_t> batch_ev;   // ... one event per batch of superblocks
 	std::vector<hipEvent_t> set_ev;     // ... and one per set of zstd output slots on their way to the device
+	std::vector<hipStream_t> set_streams; // decode of zstd-based superblocks: one stream per set of inflated batches
 	double stage_ms[16] = { 0 }; // levels >= 2: wall time per stage of the strategy layer, summed over the calls (stenos_hip_stage_ms)
 	bool warm = false;    // a device call has gone through on this context (buffers, code objects and streams are up)
 	int last_devices = 1; // devices the last host-pointer call used
@@ -297,6 +298,9 @@ struct stenos_context_s {
 		for (hipEvent_t e : set_ev)
 			(void)hipEventDestroy(e);
 		set_ev.clear();
+		for (hipStream_t st : set_streams)
+			(void)hipStreamDestroy(st);
+		set_streams.clear();
 		last_nsb = 0;
 		job_kind = 0;
 	}
@@ -347,6 +351,8 @@ struct stenos_context_s {
 			(void)hipEventDestroy(e);
 		for (hipEvent_t e : set_ev)
 			(void)hipEventDestroy(e);
+		for (hipStream_t st : set_streams)
+			(void)hipStreamDestroy(st);
 	}
 	void mark(int idx, hipStream_t stream)
 	{
@@ -1285,69 +1291,148 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 			 const FrameInfo& fi, uint8_t* d_dst, hipStream_t stream)
 {
 	PhaseTrace trace(ctx->stage_ms);
+	// A frame that lives on the device comes to the host in pieces, on a stream of its own: the threads inflate the
+	// superblocks of the first pieces while the rest is still on the link (the frame of 8 GiB of bytes at level 3 is 4 GB:
+	// 80 ms of link time, as much as half the inflation).
+	constexpr size_t PIECE = (size_t)64 << 20;
+	const size_t pieces = h_frame ? 0 : (size + PIECE - 1) / PIECE;
+	size_t pieces_here = 0;
 	if (!h_frame) {
 		HostBuf& frame_copy = ctx->h_in;
 		if (!frame_copy.ensure(size + 64))
 			return STENOS_ERROR_ALLOC;
-		if (hipMemcpyAsync(frame_copy.data(), d_frame, size, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-			return STENOS_ERROR_UNDEFINED;
+		if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+			return STENOS_ERROR_ALLOC;
+		while (ctx->set_ev.size() < pieces) {
+			hipEvent_t e;
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+				return STENOS_ERROR_ALLOC;
+			ctx->set_ev.push_back(e);
+		}
 		h_frame = frame_copy.data();
 	}
+	// (the caller's stream has been waited for: the frame is complete on the device.  Only a few pieces are queued ahead of
+	// the one being read: the copies of the inflated batches to the device wait behind whatever the other direction has queued)
+	constexpr size_t AHEAD = 4;
+	size_t pieces_queued = 0;
+	auto queue_pieces = [&](size_t upto) -> bool {
+		for (; pieces_queued < pieces && pieces_queued < upto; ++pieces_queued) {
+			const size_t at = pieces_queued * PIECE, n = size - at < PIECE ? size - at : PIECE;
+			if (hipMemcpyAsync(ctx->h_in.data() + at, d_frame + at, n, hipMemcpyDeviceToHost, ctx->copy_stream) != hipSuccess ||
+			    hipEventRecord(ctx->set_ev[pieces_queued], ctx->copy_stream) != hipSuccess)
+				return false;
+		}
+		return true;
+	};
+	auto frame_here = [&](size_t upto) -> bool { // the first `upto` bytes of the frame are on the host
+		while (pieces_here < pieces && pieces_here * PIECE < upto) {
+			if (!queue_pieces(pieces_here + 1 + AHEAD) || hipEventSynchronize(ctx->set_ev[pieces_here]) != hipSuccess)
+				return false;
+			++pieces_here;
+		}
+		return true;
+	};
 	struct Item {
 		uint64_t s;
 		uint32_t code;
 		size_t csize, dsize, r;
 	};
 	std::vector<Item> items;
-	bool any5 = false;
-	for (uint64_t s = 0; s < fi.nsb; ++s) {
-		if (h_index[s] + 4 > size)
-			return STENOS_ERROR_SRC_OVERFLOW;
-		const uint8_t* hd = h_frame + h_index[s];
-		const unsigned code = hd[0];
-		if (code == 1 || code == 6)
-			continue;
-		if (code < 2 || code > 5)
-			return STENOS_ERROR_INVALID_INPUT;
-		const size_t csize = (size_t)get_le(hd + 1, 3);
-		const uint64_t begin = s * (uint64_t)fi.sb;
-		const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
-		if (h_index[s] + 4 + csize > size)
-			return STENOS_ERROR_INVALID_INPUT;
-		any5 |= code == 5;
-		items.push_back({ s, code, csize, dsize, 0 });
-	}
-	if (items.empty())
+	uint64_t next_sb = 0;
+	// the next (up to) `want` superblocks that went through zstd, in frame order; 0 or an error code
+	auto collect = [&](size_t want) -> size_t {
+		items.clear();
+		for (; next_sb < fi.nsb && items.size() < want; ++next_sb) {
+			const uint64_t s = next_sb;
+			if (h_index[s] + 4 > size)
+				return STENOS_ERROR_SRC_OVERFLOW;
+			if (!frame_here(h_index[s] + 4))
+				return STENOS_ERROR_UNDEFINED;
+			const uint8_t* hd = h_frame + h_index[s];
+			const unsigned code = hd[0];
+			if (code == 1 || code == 6)
+				continue;
+			if (code < 2 || code > 5)
+				return STENOS_ERROR_INVALID_INPUT;
+			const size_t csize = (size_t)get_le(hd + 1, 3);
+			const uint64_t begin = s * (uint64_t)fi.sb;
+			const size_t dsize = (size_t)((fi.total - begin) < fi.sb ? (fi.total - begin) : fi.sb);
+			if (h_index[s] + 4 + csize > size)
+				return STENOS_ERROR_INVALID_INPUT;
+			if (!frame_here(h_index[s] + 4 + csize))
+				return STENOS_ERROR_UNDEFINED;
+			items.push_back({ s, code, csize, dsize, 0 });
+		}
 		return 0;
-	if (!zstd().ok)
-		return STENOS_ERROR_ZSTD_INTERNAL;
+	};
+	auto drain_frame = [&]() {
+		if (pieces)
+			(void)hipStreamSynchronize(ctx->copy_stream);
+	};
+	if (!zstd().ok) {
+		// (only an error if a superblock needs it)
+		size_t e = collect(1);
+		drain_frame();
+		return e ? e : items.empty() ? 0 : (size_t)STENOS_ERROR_ZSTD_INTERNAL;
+	}
 
 	// The superblocks are inflated by the worker threads into one staging buffer per batch (slot k: 12 spare bytes,
-	// a [1][size:3] header for code 5, the bytes at +16), moved to the device in one copy and finished there.  Two sets of
-	// buffers: the device works on one batch while the threads inflate the next.
+	// a [1][size:3] header for code 5, the bytes at +16), moved to the device in one copy and finished there.  Four sets of
+	// buffers, each with a stream of its own: a batch is a few hundred superblocks, one wave each in the block decoder, which
+	// is far from filling the device -- what a batch costs there is latency, and the batches of different sets overlap (the
+	// copy of one beside the kernels of two others) while the threads inflate the next.
+	constexpr int NSETS = 4;
 	const size_t slot = (((size_t)fi.sb + 64 + 15) & ~(size_t)15) + 16;
-	uint64_t batch = ((size_t)256 << 20) / slot;
+	uint64_t batch = ((size_t)128 << 20) / slot;
 	batch = batch < 64 ? 64 : batch > 1024 ? 1024 : batch;
-	if (batch > items.size())
-		batch = items.size();
+	if (batch > fi.nsb)
+		batch = fi.nsb;
 	const size_t set_bytes = (batch * slot + 63) & ~(size_t)63, set_ids = (batch * 4 + 63) & ~(size_t)63, set_idx = (batch * 8 + 63) & ~(size_t)63;
-	if (!ctx->tmp1.ensure(2 * set_bytes + 64) || !ctx->tmp2.ensure(2 * set_bytes + 64) || !ctx->bsize.ensure(2 * set_ids + 64) ||
-	    !ctx->binfo.ensure(2 * set_idx + 64) || !ctx->misc.ensure(4096))
-		return STENOS_ERROR_ALLOC;
+	if (!ctx->tmp1.ensure(NSETS * set_bytes + 64) || !ctx->tmp2.ensure(NSETS * set_bytes + 64) || !ctx->bsize.ensure(NSETS * set_ids + 64) ||
+	    !ctx->binfo.ensure(NSETS * set_idx + 64) || !ctx->misc.ensure(4096))
+		return drain_frame(), STENOS_ERROR_ALLOC;
 	HostBuf& stage = ctx->h_stage;
-	if (!stage.ensure(2 * set_bytes + 64))
-		return STENOS_ERROR_ALLOC;
-	while (ctx->batch_ev.size() < 2) {
+	// (behind the sets of slots: the superblock numbers and slot offsets of each batch, page-locked like the slots)
+	const size_t tab_off = NSETS * set_bytes + 64;
+	if (!stage.ensure(tab_off + NSETS * (set_ids + set_idx) + 64))
+		return drain_frame(), STENOS_ERROR_ALLOC;
+	while (ctx->batch_ev.size() < NSETS + 1) {
 		hipEvent_t e;
 		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
-			return STENOS_ERROR_ALLOC;
+			return drain_frame(), STENOS_ERROR_ALLOC;
 		ctx->batch_ev.push_back(e);
 	}
-	std::vector<uint32_t> ids[2];
-	std::vector<uint64_t> idx[2];
+	// (bytesoftype above 64 decodes through one scratch area, wide_scratch(): its batches stay in line on the caller's stream)
+	const bool one_stream = T > STENOS_K_LDS_MAX_T;
+	while (!one_stream && ctx->set_streams.size() < NSETS) {
+		hipStream_t st;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+			return drain_frame(), STENOS_ERROR_ALLOC;
+		ctx->set_streams.push_back(st);
+	}
+	auto sync_all = [&]() {
+		drain_frame();
+		(void)hipStreamSynchronize(stream);
+		for (hipStream_t st : ctx->set_streams)
+			(void)hipStreamSynchronize(st);
+	};
+	// what the caller's stream has queued (the block-coded superblocks of this frame, whatever wrote the frame) comes first
+	if (!one_stream) {
+		hipEvent_t start = ctx->batch_ev[NSETS];
+		if (hipEventRecord(start, stream) != hipSuccess)
+			return drain_frame(), STENOS_ERROR_UNDEFINED;
+		for (hipStream_t st : ctx->set_streams)
+			if (hipStreamWaitEvent(st, start, 0) != hipSuccess)
+				return drain_frame(), STENOS_ERROR_UNDEFINED;
+	}
+	std::vector<uint32_t> ids[NSETS];
+	std::vector<uint64_t> idx[NSETS];
 	volatile uint32_t* h_status = (volatile uint32_t*)((uint8_t*)ctx->h_total + 40); // (page-locked: the device writes it)
-	h_status[0] = h_status[1] = 0;
-	bool pending[2] = { false, false };
+	bool pending[NSETS];
+	for (int set = 0; set < NSETS; ++set) {
+		h_status[set] = 0;
+		pending[set] = false;
+	}
 	auto settle = [&](int set) -> size_t { // the batch that used this set of buffers is through
 		if (!pending[set])
 			return 0;
@@ -1356,12 +1441,19 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 			return STENOS_ERROR_UNDEFINED;
 		return h_status[set] ? (size_t)STENOS_ERROR_INVALID_INPUT : 0;
 	};
-	size_t nbatch = 0;
-	for (size_t i0 = 0; i0 < items.size(); i0 += batch, ++nbatch) {
-		const int set = (int)(nbatch & 1);
-		const size_t cnt = items.size() - i0 < batch ? items.size() - i0 : (size_t)batch;
+	for (size_t nbatch = 0;; ++nbatch) {
+		if (size_t e = collect((size_t)batch)) {
+			sync_all();
+			return e;
+		}
+		if (items.empty())
+			break;
+		constexpr size_t i0 = 0;
+		const int set = (int)(nbatch % NSETS);
+		hipStream_t const qs = one_stream ? stream : ctx->set_streams[(size_t)set];
+		const size_t cnt = items.size();
 		if (size_t e = settle(set)) {
-			(void)hipStreamSynchronize(stream);
+			sync_all();
 			return e;
 		}
 		trace.mark("device finish", STAGE_DEVICE_FINISH);
@@ -1383,7 +1475,7 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 		for (size_t k = 0; k < cnt; ++k) {
 			const Item& it = items[i0 + k];
 			if (zstd().is_error(it.r) || (it.code != 5 && it.code != 2 && it.r != it.dsize)) { // stenos.cpp:696-698, 706-708, 718-720
-				(void)hipStreamSynchronize(stream);
+				sync_all();
 				return STENOS_ERROR_INVALID_INPUT;
 			}
 			if (it.code == 5) { // -> one BLOCK superblock for the block decoder (stenos.cpp:726-740)
@@ -1394,27 +1486,43 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 				idx[set].push_back(k * slot + 12);
 			}
 		}
-		bool ok = hipMemcpyAsync(t1, hs, cnt * slot, hipMemcpyHostToDevice, stream) == hipSuccess;
+		// Only the part of the slots that is in use goes up: an inflated block stream is about half its 256 KiB slot, and the
+		// link is what the device's side of a batch waits for.  One strided copy (rows of the widest item, a slot apart).
+		size_t width = 0;
+		for (size_t k = 0; k < cnt; ++k) {
+			const Item& it = items[i0 + k];
+			const size_t w = 16 + (it.code == 5 ? it.r : it.dsize);
+			width = w > width ? w : width;
+		}
+		width = (width + 63) & ~(size_t)63;
+		width = width > slot ? slot : width;
+		bool ok = hipMemcpy2DAsync(t1, slot, hs, slot, width, cnt, hipMemcpyHostToDevice, qs) == hipSuccess;
 		for (size_t k = 0; k < cnt && ok; ++k) {
 			const Item& it = items[i0 + k];
 			uint8_t* out = d_dst + it.s * (uint64_t)fi.sb;
 			const uint8_t* in = t1 + k * slot + 16;
 			hipError_t e = hipSuccess;
 			if (it.code == 2) // plain zstd
-				e = hipMemcpyAsync(out, in, it.dsize, hipMemcpyDeviceToDevice, stream);
+				e = hipMemcpyAsync(out, in, it.dsize, hipMemcpyDeviceToDevice, qs);
 			else if (it.code == 3) // zstd on the transposed superblock (stenos.cpp:700-710)
-				e = stenos_k_launch_shuffle(in, out, (uint32_t)T, it.dsize, true, stream);
+				e = stenos_k_launch_shuffle(in, out, (uint32_t)T, it.dsize, true, qs);
 			else if (it.code == 4) { // transposed + byte delta (stenos.cpp:711-725)
-				e = stenos_k_launch_delta(in, t2 + k * slot, it.dsize, true, stream);
+				e = stenos_k_launch_delta(in, t2 + k * slot, it.dsize, true, qs);
 				if (e == hipSuccess)
-					e = stenos_k_launch_shuffle(t2 + k * slot, out, (uint32_t)T, it.dsize, true, stream);
+					e = stenos_k_launch_shuffle(t2 + k * slot, out, (uint32_t)T, it.dsize, true, qs);
 			}
 			ok = e == hipSuccess;
 		}
 		if (ok && !ids[set].empty()) {
-			ok = hipMemcpyAsync(d_ids, ids[set].data(), ids[set].size() * 4, hipMemcpyHostToDevice, stream) == hipSuccess &&
-			     hipMemcpyAsync(d_idx, idx[set].data(), idx[set].size() * 8, hipMemcpyHostToDevice, stream) == hipSuccess &&
-			     hipMemsetAsync(d_status, 0, 4, stream) == hipSuccess;
+			// (the two small tables come from the page-locked buffer: a copy from pageable memory is staged by the runtime and
+			// waits for the stream, which would keep the host from inflating the next batch meanwhile)
+			uint8_t* h_ids = stage.data() + tab_off + (size_t)set * (set_ids + set_idx);
+			uint8_t* h_idx = h_ids + set_ids;
+			memcpy(h_ids, ids[set].data(), ids[set].size() * 4);
+			memcpy(h_idx, idx[set].data(), idx[set].size() * 8);
+			ok = hipMemcpyAsync(d_ids, h_ids, ids[set].size() * 4, hipMemcpyHostToDevice, qs) == hipSuccess &&
+			     hipMemcpyAsync(d_idx, h_idx, idx[set].size() * 8, hipMemcpyHostToDevice, qs) == hipSuccess &&
+			     hipMemsetAsync(d_status, 0, 4, qs) == hipSuccess;
 			DecodeArgs a;
 			a.frame = t1;
 			a.size = cnt * slot;
@@ -1426,19 +1534,20 @@ size_t finish_host_codes(stenos_context_s* ctx, const uint8_t* d_frame, const ui
 			a.sb_bytes = (uint32_t)fi.sb;
 			a.T = (uint32_t)T;
 			a.status = d_status;
-			ok = ok && wide_scratch(ctx, T, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes) && stenos_k_launch_decode(a, stream) == hipSuccess &&
-			     hipMemcpyAsync((void*)(h_status + set), d_status, 4, hipMemcpyDeviceToHost, stream) == hipSuccess;
+			ok = ok && wide_scratch(ctx, T, a.nsb, &a.wide_scratch, &a.wide_scratch_bytes) && stenos_k_launch_decode(a, qs) == hipSuccess &&
+			     hipMemcpyAsync((void*)(h_status + set), d_status, 4, hipMemcpyDeviceToHost, qs) == hipSuccess;
 		}
-		ok = ok && hipEventRecord(ctx->batch_ev[(size_t)set], stream) == hipSuccess;
+		ok = ok && hipEventRecord(ctx->batch_ev[(size_t)set], qs) == hipSuccess;
 		if (!ok) {
-			(void)hipStreamSynchronize(stream);
+			sync_all();
 			return STENOS_ERROR_UNDEFINED;
 		}
 		pending[set] = true;
 	}
-	for (int set = 0; set < 2; ++set)
+	drain_frame();
+	for (int set = 0; set < NSETS; ++set)
 		if (size_t e = settle(set)) {
-			(void)hipStreamSynchronize(stream);
+			sync_all();
 			return e;
 		}
 	trace.mark("device finish", STAGE_DEVICE_FINISH);
