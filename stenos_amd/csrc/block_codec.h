@@ -1220,20 +1220,14 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 		U32 extra(0u), total(0u);
 		if (todo == 0x1111111111111111ull) {
 			// Every row of the plane is a run-length row (long runs, steps, piecewise linear data: whole frames are made of such
-			// planes).  Sixteen fixed steps then, each the same in all lanes: the position of the row's mask, the mask, its size --
-			// no lane reads, no search for the next row, no loop control; a row's lanes keep what the step of their row found.
+			// planes).  Sixteen fixed steps then: the position of the row's mask, the mask, its size -- no lane reads, no search
+			// for the next row, no loop control, no selects: a row's lanes leave the walk with what the step of their row found.
 			// (rowoff is the same in all lanes here: no row before has a payload of known size.)
 			todo = 0;
-			U32 at = rowoff, mine = rowoff;
-			for (uint32_t r = 0; r < 16; ++r) {
-				const U32 mk = lds_ld8(win, at) | (lds_ld8(win, at + 1u) << 8);
-				const Pred here = row == U32(r);
-				rmask = sel(here, mk, rmask);
-				mine = sel(here, at, mine);
-				at = at + (U32(18u) - popc(mk));
-			}
-			total = at - rowoff;
-			extra = mine - rowoff;
+			U32 at = rowoff;
+			lds_rle_walk16(win, at, rmask);
+			extra = at - rowoff;
+			total = extra + (U32(18u) - popc(rmask)); // (in the last row's lanes: the size of all sixteen)
 		}
 		while (todo) {
 			const uint32_t rl = (uint32_t)__builtin_ctzll(todo);
@@ -1247,7 +1241,7 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 			extra = extra + sel(row > U32(rl >> 2), sz, U32(0u));
 			total = total + sz;
 		}
-		rle_total = readlane(total, 0);
+		rle_total = readlane(total, 63); // (the same in all lanes behind the loop; the last row's behind the fixed walk)
 		rowoff = rowoff + extra;
 	}
 	const uint32_t psize = 8 + minslen + (readlane(upto, 63) & 0xFFFFu) + rle_total;

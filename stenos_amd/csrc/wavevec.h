@@ -313,6 +313,42 @@ WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
 	return r;
 }
 #endif
+// The walk over sixteen run-length rows that follow each other (a row: mask16, then one byte per clear bit of the mask --
+// 18 - popcount(mask) bytes).  In: `at` = the offset of the first row's mask, the same in all lanes.  Out: in the lanes of row
+// r (lane >> 2) the offset of that row's mask and the mask.  The chain of offsets is serial by nature; what it need not cost is
+// a compare and two selects per row to hand each row its step: every step drops the lowest row's four lanes from the exec mask
+// (one scalar shift), so the lanes that stay behind keep what their row's step found.  Four vector instructions a row.
+// The wave's exec mask must be full on entry.
+#define WV_RLE_WALK_LOAD "ds_read_u8 %1, %0\n\tds_read_u8 %3, %0 offset:1\n\ts_waitcnt lgkmcnt(0)\n\tv_lshl_or_b32 %1, %3, 8, %1\n\t"
+// (~mask has its upper half set: 16 + the clear bits of the mask, so the next row is at + popcount(~mask) - 14)
+#define WV_RLE_WALK_STEP "s_lshl_b64 exec, exec, 4\n\tv_not_b32 %3, %1\n\tv_bcnt_u32_b32 %3, %3, %0\n\tv_add_u32 %0, -14, %3\n\t" WV_RLE_WALK_LOAD
+#define WV_RLE_WALK_STEP5 WV_RLE_WALK_STEP WV_RLE_WALK_STEP WV_RLE_WALK_STEP WV_RLE_WALK_STEP WV_RLE_WALK_STEP
+#ifdef STENOS_WIDE
+WV_FN void lds_rle_walk16(Lds m, U32& at, U32& mask) // (the scratch is global memory there: the same walk in plain terms)
+{
+	const U32 row = lane_id_plain() >> 2;
+	U32 a = at;
+	for (uint32_t r = 0; r < 16; ++r) {
+		const U32 mk = lds_ld8(m, a) | (lds_ld8(m, a + 1u) << 8);
+		const Pred here = row == U32(r);
+		mask = sel(here, mk, mask);
+		at = sel(here, a, at);
+		a = a + (U32(18u) - popc(mk));
+	}
+}
+#else
+WV_FN void lds_rle_walk16(Lds m, U32& at, U32& mask)
+{
+	uint32_t a = lds_offset(m, at), mk, t;
+	uint64_t save;
+	asm volatile("s_mov_b64 %2, exec\n\t" WV_RLE_WALK_LOAD WV_RLE_WALK_STEP5 WV_RLE_WALK_STEP5 WV_RLE_WALK_STEP5 "s_mov_b64 exec, %2"
+		     : "+v"(a), "=&v"(mk), "=&s"(save), "=&v"(t)
+		     :
+		     : "memory", "scc");
+	at = a - lds_offset(m, U32(0u));
+	mask = mk;
+}
+#endif
 // OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
 // at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)
 WV_FN U32 lds_or_rtn32(Lds m, U32 a, U32 v) { return __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }

@@ -341,6 +341,18 @@ WV_FN U32 lds_ld8(Lds m, const U32& a)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = m[a.l[i]];
 	return r;
 }
+WV_FN void lds_rle_walk16(Lds m, U32& at, U32& mask) // (wavevec.h: sixteen run-length rows in a chain, the lane's row's offset and mask)
+{
+	uint32_t a = at.l[0];
+	for (int r = 0; r < 16; ++r) {
+		const uint32_t mk = (uint32_t)m[a] | ((uint32_t)m[a + 1] << 8);
+		for (int i = 4 * r; i < 4 * r + 4; ++i) {
+			at.l[i] = a;
+			mask.l[i] = mk;
+		}
+		a += 18 - (uint32_t)__builtin_popcount(mk);
+	}
+}
 WV_FN U32 lds_ld32(Lds m, const U32& a)
 {
 	U32 r;
