@@ -763,9 +763,16 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	const uint32_t count = 256 * T / B, nchunks = count / 64;
 	const uint32_t tab = L.tab, chain = L.lz, cur = chain + count * 4; // the image is written last: it serves as the table until then
 	const uint32_t quarter = count / 4; // the early-stop test fires at the first group start i > count/4
-	if (!lz_precheck(lds, L, T, max_size))
+	const uint32_t sampled_keys = lz_distinct_keys(lds, L, T);
+	if (!lz_precheck_passes(T, sampled_keys, max_size))
 		return 0;
-	{
+	// The two tests that follow only ever end an attempt early that would fail anyway; they are work for nothing where the
+	// attempt succeeds.  Where three out of four sampled values repeat a hash key (dictionary-like data, the mini-LZ's own
+	// ground) they are left out, and the exact count is only taken where the cheap bound comes close to the limit.
+	const bool plenty = sampled_keys * 4 <= lz_precheck_values(T);
+	bool close = false;
+	WV_MARK("lz_test2");
+	if (!plenty) {
 		// Second rejection test, for data whose values hardly repeat (noise, floats): a value can only match when an
 		// equal value precedes it, and equal values have equal hashes.  A 13-bit hash and one bit per hash value (1 KiB,
 		// the image area again) give an upper bound `maybe` of the values with an equal predecessor, so the whole stream
@@ -784,13 +791,16 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 			maybe += (uint32_t)__builtin_popcountll(ballot((old & bit) != U32(0u)));
 		}
 		wave_sync();
-		if (count / 8 + count * B - maybe * (B - 1) > max_size)
+		const uint32_t least = count / 8 + count * B - maybe * (B - 1);
+		if (least > max_size)
 			return 0;
+		close = least + 64 > max_size; // (13 hash bits over 256 or 512 values: a handful of false repeats at most)
 	}
 	if (scratch_used)
 		*scratch_used = true;
 
-	{
+	WV_MARK("lz_test3");
+	if (close) {
 		// Third rejection test: the same bound with the exact number `dups` of values that have an equal predecessor.
 		// Distinct values are counted with an open-addressing table of positions (2*count slots in the chain/candidate
 		// area, linear probing, LDS compare-and-swap).
@@ -824,6 +834,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 			return 0;
 	}
 
+	WV_MARK("lz_pass1");
 	// empty table: every entry "no position"
 	{
 		U128 none;
@@ -832,7 +843,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 	}
 	wave_sync();
 
-	uint32_t failed = 0, max_failed = 3, produced = 0;
+	uint32_t failed = 0, max_failed = 3, produced = 0, nskipped = 0;
 	bool once = false;
 	// skip bits (one per group)
 	const uint32_t skipbits = L.skip;
@@ -848,19 +859,31 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 
 	// ---- pass 1: chain[pos] = nearest earlier position with the same hash (what the table would hold if
 	// no group were skipped)
+	{
+		U128 z;
+		z.x = z.y = z.z = z.w = U32(0u);
+		lds_st128(lds, U32(cur) + lane * 16u, z, pred_all(true)); // the 256 class words
+		wave_sync();
+	}
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const U32 pos = U32(c * 64u) + lane;
 		LzVal v = lz_value(lds, L.in, B, pos);
 		U32 key = lz_hash(v, B);
-		// lanes of this chunk with the same key
-		U32 cls_lo(0xFFFFFFFFu), cls_hi(0xFFFFFFFFu);
-		for (int b = 0; b < 8; ++b) {
-			Pred bit = ((key >> U32((uint32_t)b)) & 1u) == U32(1u);
-			uint64_t bal = ballot(bit);
-			U32 blo((uint32_t)bal), bhi((uint32_t)(bal >> 32));
-			cls_lo = cls_lo & sel(bit, blo, ~blo);
-			cls_hi = cls_hi & sel(bit, bhi, ~bhi);
-		}
+		// lanes of this chunk with the same key: every lane sets its bit in its key's word of a table of 256 (the area of the
+		// second pass's candidates, not in use yet), lanes 0-31 first, then lanes 32-63, and reads the word back -- two LDS
+		// round trips instead of eight ballots and their selects
+		const U32 slot = U32(cur) + key * 4u, mybit = U32(1u) << (lane & 31u);
+		lds_or32(lds, slot, mybit, lane < U32(32u));
+		wave_sync();
+		const U32 cls_lo = lds_ld32(lds, slot);
+		wave_sync();
+		lds_st32(lds, slot, U32(0u), pred_all(true));
+		wave_sync();
+		lds_or32(lds, slot, mybit, lane >= U32(32u));
+		wave_sync();
+		const U32 cls_hi = lds_ld32(lds, slot);
+		wave_sync();
+		lds_st32(lds, slot, U32(0u), pred_all(true));
 		// nearest lower lane with the same key, else the table
 		U32 lmask = (U32(1u) << (lane & 31u)) - 1u;
 		U32 below_lo = sel(lane < U32(32u), cls_lo & lmask, cls_lo);
@@ -880,13 +903,14 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		wave_sync();
 	}
 
+	WV_MARK("lz_pass2");
 	// ---- pass 2: the groups in order
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const U32 pos = U32(c * 64u) + lane;
 		LzVal v = lz_value(lds, L.in, B, pos);
 		U32 H = lds_ld32(lds, U32(chain) + pos * 4u);
 		// current candidate: follow the chain over groups that were skipped (not hashed)
-		for (;;) {
+		while (nskipped) {
 			Pred s = skipped(H);
 			if (!any(s))
 				break;
@@ -933,6 +957,7 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 				if (--max_failed == 0)
 					max_failed = 1;
 				lds_or32(lds, U32(skipbits + (g >> 5) * 4u), U32(1u << (g & 31)), lane == U32(0u));
+				++nskipped;
 				wave_sync();
 				gsize = 1 + 8 * B;
 				// later lanes of this chunk that pointed into the skipped group move down the chain
@@ -967,21 +992,24 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		wave_sync();
 	}
 
+	WV_MARK("lz_write");
 	// success: write the stream.  Items of a group follow its flag byte.
 	image_reset(lds, L, base, produced + 1u); // the table is no longer needed
 	Lds out = lds + L.out;
-	lds_put_bits(out, U32(base * 8u), U32(BLOCK_LZ), lane == U32(0u));
+	lds_st8(out, U32(base), U32(BLOCK_LZ), lane == U32(0u));
 	uint32_t run = base + 1; // byte offset of the next chunk's first group flag
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const U32 pos = U32(c * 64u) + lane;
 		LzVal v = lz_value(lds, L.in, B, pos);
 		U32 H = lds_ld32(lds, U32(cur) + pos * 4u);
-		Pred skp = skipped(pos);
-		Pred cand = !skp & (H != U32(LZ_NONE));
+		Pred cand = H != U32(LZ_NONE);
+		if (nskipped)
+			cand = cand & !skipped(pos);
 		LzVal hv = lz_value(lds, L.in, B, sel(cand, H, U32(0u)));
 		Pred m = cand & (hv.lo == v.lo) & (hv.hi == v.hi);
 		U32 dist = pos - H;
-		U32 isz = sel(m, sel(dist < U32(128u), U32(1u), U32(2u)), U32(B));
+		const Pred far = m & (dist >= U32(128u));
+		U32 isz = sel(m, sel(far, U32(2u), U32(1u)), U32(B));
 		U32 incl = wave_incl_scan(isz);
 		uint64_t mb = ballot(m);
 		// byte offset of this item: chunk base + flag bytes of groups up to mine + items before
@@ -989,14 +1017,16 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		// flag byte (first lane of each group)
 		U32 mlo((uint32_t)mb), mhi((uint32_t)(mb >> 32));
 		U32 flags = (sel(lane < U32(32u), mlo, mhi) >> (lane & 24u)) & 0xFFu;
-		lds_put_bits(out, (ioff - 1u) * 8u, flags, (lane & 7u) == U32(0u));
+		// Every byte of the stream is written by exactly one item or flag, each at its own byte address: plain stores of
+		// 8, 16 or 32 bits wherever they fall (nothing is OR-ed into the zeroed image here).
+		lds_st8(out, ioff - 1u, flags, (lane & 7u) == U32(0u));
 		// match: distance on 1 or 2 bytes (write_diff, :140-151)
-		U32 dcode = sel(dist < U32(128u), dist, (dist & 127u) | 128u | ((dist >> 7) << 8));
-		lds_put_bits(out, ioff * 8u, dcode, m);
+		lds_st8(out, ioff, dist, m & !far);
+		lds_st16_any(out, ioff, (dist & 127u) | 128u | ((dist >> 7) << 8), far);
 		// raw value
-		lds_put_bits(out, ioff * 8u, v.lo, !m);
+		lds_st32_any(out, ioff, v.lo, !m);
 		if (B == 8)
-			lds_put_bits(out, (ioff + 4u) * 8u, v.hi, !m);
+			lds_st32_any(out, ioff + 4u, v.hi, !m);
 		run += 8 + readlane(incl, 63);
 	}
 	wave_sync();

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from stenos_amd.api import Stenos, load_library  # noqa: E402
-from stenos_amd.datagen import generate_torch  # noqa: E402
+from stenos_amd.datagen import generate, generate_torch  # noqa: E402
 
 args = sys.argv[1:]
 
@@ -35,7 +35,11 @@ for v in variants:
 for w in work:
     kind, T = w.split(":")
     T = int(T)
-    src = generate_torch(kind, T, int(gib * (1 << 30)) // T, 42)
+    try:
+        src = generate_torch(kind, T, int(gib * (1 << 30)) // T, 42)
+    except ValueError:  # (a kind only the host generator has: 256 MiB of it, repeated)
+        n = ((256 << 20) // T) // 32768 * 32768
+        src = torch.from_numpy(generate(kind, T, n, 7)).cuda().repeat(max(1, int(gib * 4)))
     ctx = {v: Stenos(1, lib=libs[v]) for v in variants}
     for st in ctx.values():
         st.set_profiling(True)
