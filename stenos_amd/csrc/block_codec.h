@@ -1501,6 +1501,13 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 	return psize;
 }
 
+#ifdef WV_HOST_EMULATION
+inline uint64_t& emul_lz_serial_count() // (tests: mini-LZ blocks the serial decoder did, lz_decode_256 having given up or not applying)
+{
+	static uint64_t n = 0;
+	return n;
+}
+#endif
 // mini-LZ stream -> image.  Returns bytes consumed (after the 253 marker) or DEC_ERROR.
 WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, uint32_t avail)
 {
@@ -1806,8 +1813,12 @@ WV_FN uint32_t decode_block(Lds lds, const DecLayout& L, uint32_t T, uint32_t cu
 			if (T == 4 || T == 8)
 				n = lz_decode_256(lds, L, T, cur + 1, avail - 1);
 #endif
-			if (n == 0)
+			if (n == 0) {
+#ifdef WV_HOST_EMULATION
+				++emul_lz_serial_count();
+#endif
 				n = lz_decode(lds, L, T, cur + 1, avail - 1);
+			}
 			if (n == DEC_ERROR)
 				return DEC_ERROR;
 			if (direct) {

@@ -240,6 +240,24 @@ def test_groups_of_blocks_are_taken_where_they_are_meant_to(oracle, emul):
 
 
 
+def test_mini_lz_blocks_take_the_two_phase_decoder(oracle, emul):
+    """lz_decode_256 (block_codec.h) gives up on nothing a valid stream holds -- near and far distances, raw groups, literals with
+    their top bit set: the serial decoder behind it is for damaged streams (and the other element sizes) only."""
+    emul.emul_lz_serial_count.restype = c_size_t
+    for kind in ("dict16", "cycle130", "lzmix"):
+        for T in (4, 8):
+            data = generate(kind, T, 64 * 256, 5)
+            nb = data.nbytes
+            ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+            r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+            assert (ref[:r1] == 253).any(), (kind, T)  # (a sanity check only: the marker byte of a mini-LZ block is around)
+            dec = np.zeros(nb + 64, dtype=np.uint8)
+            before = emul.emul_lz_serial_count()
+            r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), 0)
+            assert r3 == nb and np.array_equal(dec[:nb], data), (kind, T)
+            assert emul.emul_lz_serial_count() == before, (kind, T)
+
+
 @pytest.mark.parametrize("T", [2, 4, 8])
 def test_fused_path_across_copy_and_block_superblocks(oracle, emul, T):
     """After a superblock that ended up as a copy the fused kernel only measures the next one and encodes it for real when
