@@ -1017,16 +1017,20 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 		// flag byte (first lane of each group)
 		U32 mlo((uint32_t)mb), mhi((uint32_t)(mb >> 32));
 		U32 flags = (sel(lane < U32(32u), mlo, mhi) >> (lane & 24u)) & 0xFFu;
-		// Every byte of the stream is written by exactly one item or flag, each at its own byte address: plain stores of
-		// 8, 16 or 32 bits wherever they fall (nothing is OR-ed into the zeroed image here).
+		// Every byte of the stream is written by exactly one item or flag, each at its own byte address: plain byte stores
+		// (nothing is OR-ed into the zeroed image here).
 		lds_st8(out, ioff - 1u, flags, (lane & 7u) == U32(0u));
 		// match: distance on 1 or 2 bytes (write_diff, :140-151)
 		lds_st8(out, ioff, dist, m & !far);
-		lds_st16_any(out, ioff, (dist & 127u) | 128u | ((dist >> 7) << 8), far);
-		// raw value
-		lds_st32_any(out, ioff, v.lo, !m);
+		lds_st8(out, ioff, (dist & 127u) | 128u, far);
+		lds_st8(out, ioff + 1u, dist >> 7, far);
+		// raw value (byte by byte: the LDS does store 32 bits at any byte address, but an access that straddles a dword takes a slow
+		// path -- ten times the latency with the device busy, tools/ubench_lds_bytes.hip; as stores here the two cost the same)
+		for (uint32_t b = 0; b < 4; ++b)
+			lds_st8(out, ioff + b, v.lo >> (8 * b), !m);
 		if (B == 8)
-			lds_st32_any(out, ioff + 4u, v.hi, !m);
+			for (uint32_t b = 0; b < 4; ++b)
+				lds_st8(out, ioff + 4u + b, v.hi >> (8 * b), !m);
 		run += 8 + readlane(incl, 63);
 	}
 	wave_sync();

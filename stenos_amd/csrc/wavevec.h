@@ -313,32 +313,15 @@ WV_FN U32 lds_add_rtn32(Lds m, U32 a, U32 v, Pred p)
 	return r;
 }
 #endif
-// Stores of 16 and 32 bits at any byte address (the LDS runs in unaligned access mode: tools/ubench_unaligned.hip), for
-// byte streams whose items start where the one before ended.
-typedef uint16_t __attribute__((aligned(1))) wv_u16_any;
-typedef uint32_t __attribute__((aligned(1))) wv_u32_any;
-#if defined(STENOS_WIDE) || defined(WV_PREDICATE_BRANCHES)
-WV_FN void lds_st16_any(Lds m, U32 a, U32 v, Pred p)
-{
-	if (p) *(wv_u16_any*)(m + a) = (uint16_t)v;
-}
-WV_FN void lds_st32_any(Lds m, U32 a, U32 v, Pred p)
-{
-	if (p) *(wv_u32_any*)(m + a) = v;
-}
-#else
-WV_FN void lds_st16_any(Lds m, U32 a, U32 v, Pred p) { WV_MASKED("ds_write_b16 %2, %3", ballot(p), "v"(lds_offset(m, a)), "v"(v)); }
-WV_FN void lds_st32_any(Lds m, U32 a, U32 v, Pred p) { WV_MASKED("ds_write_b32 %2, %3", ballot(p), "v"(lds_offset(m, a)), "v"(v)); }
-#endif
-WV_FN U32 lds_ld32_any(Lds m, U32 a) { return *(const wv_u32_any*)(m + a); }
 // The walk over sixteen run-length rows that follow each other (a row: mask16, then one byte per clear bit of the mask --
 // 18 - popcount(mask) bytes).  In: `at` = the offset of the first row's mask, the same in all lanes.  Out: in the lanes of row
 // r (lane >> 2) the offset of that row's mask and the mask.  The chain of offsets is serial by nature; what it need not cost is
 // a compare and two selects per row to hand each row its step: every step drops the lowest row's four lanes from the exec mask
 // (one scalar shift), so the lanes that stay behind keep what their row's step found.  Four vector instructions a row.
 // The wave's exec mask must be full on entry.
-// (two byte reads: the LDS does read 16 bits at an odd address, tools/ubench_unaligned.hip, but takes so long over it that
-// the whole decode of run-length data was 1.8 x slower with ds_read_u16 here)
+// (two byte reads: the LDS does read 16 bits at an odd address, tools/ubench_unaligned.hip, but a read that straddles a dword
+// takes a slow path -- 170 cycles alone, 1200 with the device busy, tools/ubench_lds_bytes.hip: the whole decode of run-length
+// data was 1.8 x slower with ds_read_u16 here)
 #define WV_RLE_WALK_LOAD "ds_read_u8 %1, %0\n\tds_read_u8 %3, %0 offset:1\n\ts_waitcnt lgkmcnt(0)\n\tv_lshl_or_b32 %1, %3, 8, %1\n\t"
 // (~mask has its upper half set: 16 + the clear bits of the mask, so the next row is at + popcount(~mask) - 14)
 #define WV_RLE_WALK_STEP "s_lshl_b64 exec, exec, 4\n\tv_not_b32 %3, %1\n\tv_bcnt_u32_b32 %3, %3, %0\n\tv_add_u32 %0, -14, %3\n\t" WV_RLE_WALK_LOAD

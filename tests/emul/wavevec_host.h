@@ -376,25 +376,6 @@ WV_FN void lds_st8(Lds m, const U32& a, const U32& v, const Pred& p)
 	for (int i = 0; i < WAVE; ++i)
 		if (p.l[i]) m[a.l[i]] = (uint8_t)v.l[i];
 }
-WV_FN void lds_st16_any(Lds m, const U32& a, const U32& v, const Pred& p)
-{
-	for (int i = 0; i < WAVE; ++i)
-		if (p.l[i]) {
-			const uint16_t w = (uint16_t)v.l[i];
-			memcpy(m + a.l[i], &w, 2);
-		}
-}
-WV_FN void lds_st32_any(Lds m, const U32& a, const U32& v, const Pred& p)
-{
-	for (int i = 0; i < WAVE; ++i)
-		if (p.l[i]) memcpy(m + a.l[i], &v.l[i], 4);
-}
-WV_FN U32 lds_ld32_any(Lds m, const U32& a)
-{
-	U32 r;
-	for (int i = 0; i < WAVE; ++i) memcpy(&r.l[i], m + a.l[i], 4);
-	return r;
-}
 // atomic add returning the previous value (lane order on the host; any order is a valid device order)
 WV_FN U32 lds_add_rtn32(Lds m, const U32& a, const U32& v, const Pred& p)
 {
