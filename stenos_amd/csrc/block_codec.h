@@ -1588,8 +1588,9 @@ WV_FN uint32_t lz_decode(Lds lds, const DecLayout& L, uint32_t T, uint32_t cur, 
 
 // The same for 256 items (bytesoftype 4 and 8) in two phases instead of a chain of 32 groups with eight LDS round trips each.
 // Phase 1, the chain: where a group starts depends on the sizes of the items in front of it, and a match is one byte or two.
-// Taking every match for one byte makes a group's size a function of its flags byte alone: 32 dependent byte reads; if a match
-// of two bytes shows up (a distance of 128 or more), the chain is walked again with the groups sized exactly.
+// Taking every match for one byte makes a group's size a function of its flags byte alone: 32 dependent byte reads, three
+// vector instructions each (lds_lz_walk32); if a match of two bytes shows up (a distance of 128 or more), the chain is walked
+// again with the groups sized exactly, on scalars.
 // Phase 2, all items at once, four per lane: offsets from the flags, distances and literals read; the literals go to their
 // places in the image, and a table of 256 bytes says for every item where its value comes from -- itself (a literal) or the
 // item the match points at.  Pointer jumping on that table (a match's source may be a match: at most eight rounds, one byte
@@ -1608,19 +1609,30 @@ WV_FN uint32_t lz_decode_256(Lds lds, const DecLayout& L, uint32_t T, uint32_t c
 	Pred match[4];
 	uint32_t p = cur;
 	// First with every match taken for one byte; if one turns out to have two, once more with the groups sized exactly.
+	U32 rec(0u); // lane g: where group g starts | its flags << 16 | which of its matches have two bytes << 24
+	uint32_t first_long = 0; // the first group that holds a match of two bytes: the groups before it are where the first pass saw them
 	for (uint32_t exact = 0;; ++exact) {
-		p = cur;
-		U32 rec(0u); // lane g: where group g starts | its flags << 16 | which of its matches have two bytes << 24
-		for (uint32_t g = 0; g < 32; ++g) {
-			if (p + 2 > end)
+		if (!exact) {
+			// every lane g < 32 walks to group g (lds_lz_walk32: the chain of 32 dependent byte reads, in vector registers throughout)
+			U32 at(cur), fl(0u);
+			lds_lz_walk32(win, at, fl, B);
+			if (any((lane < U32(32u)) & (at + 2u > U32(end))))
 				return 0;
-			const uint32_t flags = win_u8(win, p);
-			uint32_t two = 0, len;
-			if (exact) {
+			rec = at | (fl << 16);
+			p = readlane(at, 31) + 1 + 8 * B - (B - 1) * (uint32_t)__builtin_popcount(readlane(fl, 31));
+		}
+		else {
+			p = readlane(rec, first_long) & 0xFFFFu;
+			for (uint32_t g = first_long; g < 32; ++g) {
+				if (p + 2 > end)
+					return 0;
 				// the group's bytes behind the flags, one per lane (an item starts at most 56 bytes in): a match has two bytes when
-				// its first one has bit 7 set -- eight steps on scalars, one v_readlane_b32 each
+				// its first one has bit 7 set -- eight steps on scalars, one v_readlane_b32 per match, a literal is one addition
+				// (the same walk over a mask of the bytes with bit 7 set, without lane reads or branches, took 1.5 x as long: every
+				// item then costs its eight scalar instructions, and the scalar unit is shared by the four SIMDs)
+				const uint32_t flags = win_u8(win, p);
 				const U32 bytes = lds_ld8(win, U32(p + 1) + lane);
-				uint32_t at = 0;
+				uint32_t two = 0, at = 0;
 				for (uint32_t j = 0; j < 8; ++j) {
 					if ((flags >> j) & 1u) {
 						const uint32_t t = readlane(bytes, at) >> 7;
@@ -1630,14 +1642,9 @@ WV_FN uint32_t lz_decode_256(Lds lds, const DecLayout& L, uint32_t T, uint32_t c
 					else
 						at += B;
 				}
-				len = 1 + at;
+				rec = sel(lane == U32(g), U32(p | (flags << 16) | (two << 24)), rec);
+				p += 1 + at;
 			}
-			else {
-				const uint32_t nm = (uint32_t)__builtin_popcount(flags);
-				len = 1 + nm + (8 - nm) * B;
-			}
-			rec = sel(lane == U32(g), U32(p | (flags << 16) | (two << 24)), rec);
-			p += len;
 		}
 		if (p > end)
 			return 0;
@@ -1661,9 +1668,10 @@ WV_FN uint32_t lz_decode_256(Lds lds, const DecLayout& L, uint32_t T, uint32_t c
 			if (B == 8)
 				lds_st32(lds, U32(L.img + 4) + idx * 8u, lds_ld32_unaligned(win, off + 4u), !match[k]);
 		}
-		if (any(longer)) {
+		if (const uint64_t lb = ballot(longer)) {
 			if (exact)
 				return 0;
+			first_long = (uint32_t)__builtin_ctzll(lb) >> 1; // (two lanes a group)
 			continue;
 		}
 		if (any(bad))

@@ -352,6 +352,41 @@ WV_FN void lds_rle_walk16(Lds m, U32& at, U32& mask)
 	mask = mk;
 }
 #endif
+// The same kind of walk over the 32 groups of a mini-LZ block with every match taken for one byte: a group is its flags byte
+// and eight items, a match (flag set) one byte, a literal B bytes -- 1 + 8 B - (B - 1) * popcount(flags) bytes.  In: `at` = the
+// offset of the first group's flags, the same in all lanes.  Out: in lane g < 32 the offset of group g and its flags (lanes
+// 32-63: what lane 31 holds, one step on).  Three vector instructions a group and nothing on the scalar unit but the shift of
+// the exec mask; offsets past the data just read what lies there (the caller checks them).  Full exec mask on entry.
+#ifdef STENOS_WIDE
+WV_FN void lds_lz_walk32(Lds m, U32& at, U32& flags, uint32_t B) // (the scratch is global memory there; not used, kept compilable)
+{
+	const U32 lane = lane_id_plain();
+	U32 a = at;
+	for (uint32_t g = 0; g < 32; ++g) {
+		const U32 fl = lds_ld8(m, a);
+		const Pred here = lane >= U32(g);
+		flags = sel(here, fl, flags);
+		at = sel(here, a, at);
+		a = a + (U32(1u + 8u * B) - popc(fl) * (B - 1u));
+	}
+}
+#else
+#define WV_LZ_WALK_STEP "s_lshl_b64 exec, exec, 1\n\tv_bcnt_u32_b32 %3, %1, 0\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_add_u32 %0, %5, %0\n\tds_read_u8 %1, %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define WV_LZ_WALK_STEP4 WV_LZ_WALK_STEP WV_LZ_WALK_STEP WV_LZ_WALK_STEP WV_LZ_WALK_STEP
+#define WV_LZ_WALK_STEP16 WV_LZ_WALK_STEP4 WV_LZ_WALK_STEP4 WV_LZ_WALK_STEP4 WV_LZ_WALK_STEP4
+WV_FN void lds_lz_walk32(Lds m, U32& at, U32& flags, uint32_t B)
+{
+	uint32_t a = lds_offset(m, at), fl, t;
+	uint64_t save;
+	asm volatile("s_mov_b64 %2, exec\n\tds_read_u8 %1, %0\n\ts_waitcnt lgkmcnt(0)\n\t" WV_LZ_WALK_STEP16 WV_LZ_WALK_STEP4 WV_LZ_WALK_STEP4 WV_LZ_WALK_STEP4
+		     WV_LZ_WALK_STEP WV_LZ_WALK_STEP WV_LZ_WALK_STEP "s_mov_b64 exec, %2"
+		     : "+v"(a), "=&v"(fl), "=&s"(save), "=&v"(t)
+		     : "s"(0u - (B - 1u)), "s"(1u + 8u * B)
+		     : "memory", "scc");
+	at = a - lds_offset(m, U32(0u));
+	flags = fl;
+}
+#endif
 // OR-ing 0 is a no-op, so a predicated OR needs no branch: inactive lanes OR 0 into a dword of their own
 // at the start of the buffer (one shared address would serialise the whole wave in the LDS atomic unit)
 WV_FN U32 lds_or_rtn32(Lds m, U32 a, U32 v) { return __hip_atomic_fetch_or((uint32_t*)(m + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }

@@ -341,6 +341,22 @@ WV_FN U32 lds_ld8(Lds m, const U32& a)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = m[a.l[i]];
 	return r;
 }
+WV_FN void lds_lz_walk32(Lds m, U32& at, U32& flags, uint32_t B) // (wavevec.h: the 32 groups of a mini-LZ block, every match taken for one byte)
+{
+	uint32_t a = at.l[0];
+	for (int g = 0; g < 32; ++g) {
+		const uint32_t fl = m[a];
+		for (int i = g; i < (g == 31 ? 32 : g + 1); ++i) {
+			at.l[i] = a;
+			flags.l[i] = fl;
+		}
+		a += 1 + 8 * B - (B - 1) * (uint32_t)__builtin_popcount(fl);
+	}
+	for (int i = 32; i < WAVE; ++i) { // (one step on; not used)
+		at.l[i] = a;
+		flags.l[i] = m[a];
+	}
+}
 WV_FN void lds_rle_walk16(Lds m, U32& at, U32& mask) // (wavevec.h: sixteen run-length rows in a chain, the lane's row's offset and mask)
 {
 	uint32_t a = at.l[0];
