@@ -53,8 +53,6 @@ for k in ("encode_superblocks", "encode_blocks", "pack_frame", "decode_superbloc
         res[f"{k}_hbm_read_bytes"] = int(scale * 2 * out[k]["FETCH_SIZE"] * 1024)
         res[f"{k}_hbm_write_bytes"] = int(scale * out[k]["WRITE_SIZE"] * 1024)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json"), "w") as f:
-    json.dump(res, f, indent=1)
 import subprocess  # noqa: E402
 
 try:
