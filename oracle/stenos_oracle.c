@@ -8,6 +8,7 @@
 #include "stenos_oracle.h"
 
 #include <dlfcn.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1083,7 +1084,11 @@ static double transposed_lz_ratio(const uint8_t* shuffled, size_t T, size_t byte
 		processed += step;
 	}
 	free(tmp);
-	return ((double)processed / (double)csize) * (1. + (double)level * 0.02);
+	/* The reference is built for x86-64-v3, where both g++ and clang++ contract 1 + level * 0.02 into one fused
+	 * multiply-add (no rounding of the product): 1.14 exactly rounded for level 7 where the two-step form gives
+	 * 1.1400000000000001.  The last bit decides exact ties between the transposed and the transposed + delta estimate
+	 * (csize_delta == 1.1 * csize: found by the fuzz soak of round 5, level 7, 8-byte elements). */
+	return ((double)processed / (double)csize) * fma((double)level, 0.02, 1.);
 }
 
 /* zstd_from_reduced_level, zstd_wrapper.h:49-56 */
@@ -1174,6 +1179,9 @@ static size_t sb_compress(const uint8_t* src, size_t T, size_t bytes, uint8_t* d
 			lz_trd = transposed_lz_ratio(b1, T, bytes, level, 1) * 1.1;
 			if (lz_trd > lz_ratio)
 				lz_ratio = lz_trd;
+#ifdef SO_DEBUG
+			fprintf(stderr, "[oracle] lz_ratio %.17g lz_tr %.17g lz_trd %.17g\n", lz_ratio, lz_tr, lz_trd);
+#endif
 			const double factor = 1. + level / 12.;
 			lz_tr *= factor;
 			lz_trd *= factor;

@@ -924,22 +924,30 @@ WV_FN uint32_t lz_try(Lds lds, const Layout& L, uint32_t T, uint32_t max_size, u
 			const Pred cand = H != U32(LZ_NONE);
 			const LzVal hv = lz_value(lds, L.in, B, sel(cand, H, U32(0u)));
 			const Pred m = cand & (hv.lo == v.lo) & (hv.hi == v.hi);
-			const uint64_t mb = ballot(m), fb = ballot(m & ((pos - H) >= U32(128u)));
-			uint32_t empty = 0;
-			for (uint32_t k = 0; k < 8; ++k)
-				empty += ((mb >> (8 * k)) & 0xFFu) == 0;
+			const Pred far = m & ((pos - H) >= U32(128u));
+			// groups without a match: fold every byte of the mask of matches onto its lowest bit
+			uint64_t any8 = ballot(m);
+			any8 |= any8 >> 4;
+			any8 |= any8 >> 2;
+			any8 |= any8 >> 1;
+			const uint32_t empty = 8 - (uint32_t)__builtin_popcountll(any8 & 0x0101010101010101ull);
 			if (failed + empty < max_failed) {
+				// The bytes the chunk produces, as a running sum over the lanes (an item's bytes, and the flags byte with a group's
+				// first lane): the sum behind a group's last lane is what the stream holds after that group.  The sizes only ever
+				// grow, so the limit is tested once, behind the chunk (:221-223), and the early test (:224-229) at the one group it
+				// belongs to -- one prefix sum in vector registers instead of eight groups of arithmetic on the scalar unit (two
+				// dozen scalar instructions a group, 800 a block: scalar instructions cost half a vector instruction each here).
+				const U32 isz = sel(m, sel(far, U32(2u), U32(1u)), U32(B)) + sel((lane & 7u) == U32(0u), U32(1u), U32(0u));
+				const U32 upto = wave_incl_scan(isz);
 				bool over = false;
-				for (uint32_t k = 0; k < 8; ++k) {
-					const uint32_t nm = (uint32_t)__builtin_popcountll((mb >> (8 * k)) & 0xFFu), nf = (uint32_t)__builtin_popcountll((fb >> (8 * k)) & 0xFFu);
-					failed += (nm == 0);
-					produced += 1 + 8 * B - nm * (B - 1) + nf;
-					over |= produced > max_size; // (:221-223)
-					if (!once && (c * 8 + k) * 8 > quarter) { // (:224-229)
-						over |= 5 * produced > 2 * max_size;
-						once = true;
-					}
+				const uint32_t early = quarter / 8 + 1 > c * 8 ? quarter / 8 + 1 : c * 8; // the first group whose first value has an index above count / 4
+				if (!once && early <= c * 8 + 7) {
+					over = 5 * (produced + readlane(upto, 8 * (early - c * 8) + 7)) > 2 * max_size;
+					once = true;
 				}
+				produced += readlane(upto, 63);
+				over |= produced > max_size;
+				failed += empty;
 				if (over)
 					return 0;
 				lds_st32(lds, U32(cur) + pos * 4u, H, pred_all(true));

@@ -22,6 +22,11 @@ for level in (2, 3, 4, 5, 7, 9):
 for level in (1, 2, 3, 6):
     for n in (50, 5000, 300000):
         CASES.append(("smooth8", 1, n, level))
+# cases of their own (kind, bytesoftype, elements, level, seed of the data):
+#  - an exact tie between the estimate on the transposed input and 1.1 x the one on transposed + delta (2 080 against 2 288
+#    bytes): which of them wins hangs on the last bit of 1 + level * 0.02, which the reference's compilers fuse into one
+#    multiply-add (fuzz soak of round 5)
+SEEDED = [("cycle130", 8, 61352, 7, 1071752612)]
 
 
 def main():
@@ -34,6 +39,11 @@ def main():
         r, frame = ref_compress(ref, data, T, level)
         assert not has_error(r)
         out.append({"kind": kind, "T": T, "n": n, "level": level, "size": int(r), "sha256": hashlib.sha256(frame.tobytes()).hexdigest()})
+    for kind, T, n, level, seed in SEEDED:
+        data = generate(kind, T, n, seed)
+        r, frame = ref_compress(ref, data, T, level)
+        assert not has_error(r)
+        out.append({"kind": kind, "T": T, "n": n, "level": level, "seed": seed, "size": int(r), "sha256": hashlib.sha256(frame.tobytes()).hexdigest()})
     with open(os.path.join(HERE, "levels_manifest.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_levels_manifest.py", "zstd": "1.4.9", "cases": out}, f, indent=0)
     print(len(out), "cases")

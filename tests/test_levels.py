@@ -39,7 +39,7 @@ def _id(e):
 @needs_zstd_149
 @pytest.mark.parametrize("e", CASES, ids=_id)
 def test_oracle_matches_reference_hashes(oracle, e):
-    data = generate(e["kind"], e["T"], e["n"], 42)
+    data = generate(e["kind"], e["T"], e["n"], e.get("seed", 42))
     r, frame = oracle_compress(oracle, data, e["T"], e["level"])
     assert not has_error(r) and r == e["size"]
     assert hashlib.sha256(frame.tobytes()).hexdigest() == e["sha256"]
@@ -59,7 +59,7 @@ def lib():
 @needs_zstd_149
 @pytest.mark.parametrize("e", CASES, ids=_id)
 def test_gpu_matches_reference_hashes(lib, e):
-    data = generate(e["kind"], e["T"], e["n"], 42)
+    data = generate(e["kind"], e["T"], e["n"], e.get("seed", 42))
     out = np.full(lib.stenos_bound(data.nbytes) + 64, 0xA5, dtype=np.uint8)
     r = lib.stenos_compress(np_ptr(data), e["T"], data.nbytes, np_ptr(out), out.nbytes - 64, e["level"])
     assert not has_error(r), hex(r)
