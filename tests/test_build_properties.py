@@ -109,6 +109,37 @@ def test_vector_memory_in_asm_statements_waits_for_its_scalar_base(source, flags
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+@pytest.mark.parametrize("source,flags", [("kernels.hip", ["-DWV_PREDICATE_BRANCHES"]), ("decode_kernels.hip", ["-mllvm", "-structurizecfg-skip-uniform-regions=1"])])
+def test_asm_statements_that_change_the_exec_mask_put_it_back(source, flags):
+    """Predicated accesses and the chain walks of the decoders (wavevec.h: lds_rle_walk16, lds_lz_walk32) narrow the exec mask
+    inside an asm statement; the compiler does not know, so every such statement has to save the mask first and to end with
+    the instruction that restores it from the same registers."""
+    lines = _device_asm(source, flags)
+    inside, body, seen, walks = False, [], 0, 0
+    for i, l in enumerate(lines):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            inside, body = True, []
+            continue
+        if t.startswith(";;#ASMEND"):
+            inside = False
+            writes = [b for b in body if b.replace(",", " ").split()[1:2] == ["exec"] and b.split()[0].startswith("s_")]
+            if writes:
+                seen += 1
+                walks += any(b.startswith("s_lshl_b64 exec") for b in body)
+                saves = [b for b in body if b.startswith("s_mov_b64") and b.replace(",", " ").split()[2:3] == ["exec"]]
+                assert saves and body.index(saves[0]) < body.index(writes[0]), (i + 1, body[:6])
+                saved = saves[0].replace(",", " ").split()[1]
+                assert body[-1].replace(",", " ").split() == ["s_mov_b64", "exec", saved], (i + 1, body[-3:])
+            continue
+        if inside and t and not t.startswith(";"):
+            body.append(t)
+    assert seen > 0
+    if source == "decode_kernels.hip":
+        assert walks >= 2  # (both walks are in the build)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
 def test_kernel_resources_stay_inside_their_budget():
     """What the measured numbers rest on (-Rpass-analysis=kernel-resource-usage): the decoders and the hot encoders keep
     their occupancy, the fused encoders of bytesoftype 2 and 8 and every decoder use no scratch memory, and the scratch of the
