@@ -406,7 +406,9 @@ WV_FN void slot_write_rle_lut(Lds lds, const Layout& L)
 // scr: which KiB of the slot area serves as scratch -- the dump of the lanes with nothing to write, the hand-over of the
 // run-length rows -- (0: the pass's own slots, whose rows are in registers; a group of four blocks names the slots of its
 // second pass, the first one's being read again later)
-WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, const Pred& valid, const U32& pbase, uint32_t scr = 0)
+// rowwise: the form for passes made of run-length rows is compiled in (known where the call is compiled: the groups of four
+// of 32-bit elements, the headline's path, go without -- their copies of this code would cost the int32 kernel registers)
+WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, const Pred& valid, const U32& pbase, uint32_t scr = 0, bool rowwise = true)
 {
 	const U32 lane = lane_id();
 	const U32 r = lane & 15u;
@@ -462,6 +464,27 @@ WV_FN void slot_rows_emit_rows(Lds lds, const Layout& L, const SlotRows& R, cons
 		d.x = sel(is7, R.sb[0], R.sd[0]), d.y = sel(is7, R.sb[1], R.sd[1]), d.z = sel(is7, R.sb[2], R.sd[2]), d.w = sel(is7, R.sb[3], R.sd[3]);
 		// in front of a row of values: the last byte of the row above (:268-275); of a row of differences: no difference (:248-255)
 		const U32 front = sel(is7, row_shr(R.sb[3], 1, 0x80808080u), U32(0x80808080u));
+		if (rowwise && n > 32) {
+			// Most rows of the pass are run-length rows (long runs, steps: whole frames are made of such planes): then every lane
+			// does its own row, four dwords one after the other -- 90 instructions whatever the number of rows, where the hand-over
+			// below takes 40 per sixteen rows.
+			U32 f16(0u), lp = rbase + 2u;
+			for (int j = 0; j < 4; ++j) {
+				// byte == previous byte (:268-275) / difference == previous difference (:248-255)
+				const U32 bp = j ? prev_bytes(R.sb[j], R.sb[j - 1]) : prev_bytes(R.sb[0], row_shr(R.sb[3], 1, 0x80808080u));
+				const U32 dp = j ? prev_bytes(R.sd[j], R.sd[j - 1]) : ((R.sd[0] << 8) | 0x80u);
+				const U32 f = zero_mask_to_bits(bytes_zero_mask(sel(is7, R.sb[j] ^ bp, R.sd[j] ^ dp)));
+				f16 = f16 | (f << U32(4u * (uint32_t)j));
+				const U32 nlit = U32(4u) - popc(f);
+				const U32 lits = perm_bytes_v(U32(0u), sel(is7, R.sb[j], R.sd[j]) ^ H, lds_ld32(lds, U32(lut) + f * 4u));
+				put_bits(out, lp * 8u, lits, rle & (nlit != U32(0u)), own);
+				lp = lp + nlit;
+			}
+			put_bits(out, rbase * 8u, f16, rle, own);
+			WV_MARK("emit_end");
+			wave_sync();
+			return;
+		}
 		const U32 k = lane & 3u, k4 = k << 2, quad = lane >> 2;
 		const U32 idle = U32(area - L.out + 512u) + (lane & 31u) * 16u; // where quads without a row OR what they have
 		for (uint32_t c = 0; c < n; c += 16) {
@@ -619,7 +642,7 @@ WV_FN void slot_rows_emit4(Lds lds, const Layout& L, uint32_t T, const SlotRows&
 		wave_sync();
 		return;
 	}
-	slot_rows_emit_rows(lds, L, R, P.valid, pbase);
+	slot_rows_emit_rows(lds, L, R, P.valid, pbase, 0, false);
 }
 
 // ---- groups of four blocks (bytesoftype 2 and 4) --------------------------------------------------------------------------

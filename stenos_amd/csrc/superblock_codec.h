@@ -328,13 +328,13 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				image_reset_group4(lds, M);
 				const U32 bbase = U32(sink.base()) + incl - bsz;
 				// the second pass first: its rows are in registers; the slots of that pass are the scratch of both emissions
-				slot_rows_emit_rows(lds, M, R, pred_all(true), bbase + U32(hs + k1 - 1u) + (ts0 & 0xFFFFu), 1024);
+				slot_rows_emit_rows(lds, M, R, pred_all(true), bbase + U32(hs + k1 - 1u) + (ts0 & 0xFFFFu), 1024, T == 2);
 				group4_emit_heads(lds, M, T, k0, k1, bbase, ts0, R.ts, firstv, 1024);
 				WV_MARK("g4_emit0");
 				slot_rows_reload(lds, M, R, 0, !raw0);
 				R.ts = ts0, R.hm = hm0, R.pm = pm0;
 				R.emitmin = emitmin0, R.eq = eq0;
-				slot_rows_emit_rows(lds, M, R, pred_all(true), bbase + U32(hs + k0), 1024);
+				slot_rows_emit_rows(lds, M, R, pred_all(true), bbase + U32(hs + k0), 1024, T == 2);
 			}
 			WV_MARK("g4_append");
 			sink.append(lds, M, total);
@@ -463,14 +463,14 @@ WV_FN void encode_blocks_to(Sink& sink, Lds lds, const Layout& L, uint32_t T, co
 				const U32 sl = lane >> 4;
 				if (n1) {
 					const U32 pb1 = lds_ld32(lds, U32(M.grp + GRP_POS + 16) + sl * 4u);
-					slot_rows_emit_rows(lds, M, R, sl < U32(n1), pb1, 1024);
+					slot_rows_emit_rows(lds, M, R, sl < U32(n1), pb1, 1024, T == 2);
 					slot_rows_reload(lds, M, R, 0, !raw0);
 					R.ts = ts0, R.hm = hm0, R.pm = pm0;
 					R.emitmin = emitmin0, R.eq = eq0;
 				}
 				if (n0) {
 					const U32 pb0 = lds_ld32(lds, U32(M.grp + GRP_POS) + sl * 4u);
-					slot_rows_emit_rows(lds, M, R, sl < U32(n0), pb0, 1024);
+					slot_rows_emit_rows(lds, M, R, sl < U32(n0), pb0, 1024, T == 2);
 				}
 			}
 			WV_MARK("ga_append");
