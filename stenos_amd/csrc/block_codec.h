@@ -1362,6 +1362,57 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 	return psize;
 }
 
+// A plane of a full block all of whose sixteen rows are run-length coded VALUES (header 7: long runs, steps -- whole frames are
+// made of such planes).  No row has a minimum or a payload of known size, so the rows follow the eight header bytes directly
+// and only the walk finds them; an element is the literal in force at its place -- the last literal of its row in front of it
+// or, in front of the row's first literal, what the row above ended with: its last literal, or what IT began with if it has
+// none.  That carry is the last literal of the nearest row above that has one: one byte read per row and one running maximum
+// of keys over the rows.  With the carry put where the lane's pool has the literal in force, the selector table gives the
+// lane's four elements in one v_perm_b32: no differences, no prefix sums (the general form above needs both for the rows
+// that are not of this kind).  Same bytes consumed, same result as decode_plane_packed<true, 2>.
+#ifdef WV_HOST_EMULATION
+inline uint64_t& emul_plane_runs_count() // (tests: planes decoded by decode_plane_runs)
+{
+	static uint64_t n = 0;
+	return n;
+}
+#endif
+WV_FN uint32_t decode_plane_runs(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t cur, U32* keep)
+{
+#ifdef WV_HOST_EMULATION
+	++emul_plane_runs_count();
+#endif
+	const U32 lane = lane_id_plain();
+	Lds win = lds + L.win;
+	const U32 row = lane >> 2, q = lane & 3u;
+	U32 at(cur + 8), rmask(0u);
+	lds_rle_walk16(win, at, rmask); // the row's mask and where it is
+	const U32 nlit = U32(16u) - popc(rmask);
+	const uint32_t psize = readlane(at + 2u + nlit, 63) - cur;
+	const U32 shift = q << 2;
+	const U32 f = (rmask >> shift) & 0xFu;
+	const U32 before = popc(~rmask & ((U32(1u) << shift) - 1u)); // literals of the row in front of this lane's
+	// the five bytes from the literal in force on (the last one in front of the lane's own; none: a byte of the mask, replaced below)
+	const U32 from = at + 1u + before;
+	U32 lo, hi;
+	lds_ld64(win, from, lo, hi);
+	U32 pool_lo = funnel_shr(hi, lo, from << 3);
+	const U32 pool_hi = hi >> ((from & 3u) << 3);
+	// what each row ends with, handed down to the rows below: key = row + 1 | last literal for the rows that have one
+	const U32 last = lds_ld8(win, at + 1u + nlit);
+	const U32 key = sel(nlit != U32(0u), ((row + 1u) << 8) | last, U32(0u));
+	const U32 above = shfl_up(quads_incl_scan_max(key), 4, 0); // (of the row above: the newest row with a literal up to it; none: 0)
+	pool_lo = sel(before == U32(0u), (pool_lo & ~U32(0xFFu)) | (above & 0xFFu), pool_lo);
+	const U32 selw = lds_ld32(lds, U32(L.lut + 64) + (f << 2));
+	const U32 outw = perm_bytes_v(pool_hi, pool_lo, selw);
+	if (keep)
+		*keep = outw;
+	else
+		store_plane_word(lds, L.img, T, j, outw, pred_all(true));
+	WV_MARK("dec_runs_end");
+	return psize;
+}
+
 // Decode one NORMAL / NORMAL_RLE plane whose bytes start at window offset `cur` (at most `avail`
 // valid bytes).  Writes rows [0, lines) of plane j into the image or, with `keep`, hands the lane's plane word back instead.
 // Returns bytes consumed or DEC_ERROR.
@@ -1389,8 +1440,11 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 		const U32 kind = (U32(0x4000E000u) >> (hdr + hdr)) & 3u;
 		if (ballot(kind != U32(0u)) != 0) {
 			WV_NESTED();
-			if (ballot(kind == U32(3u)) != 0)
+			if (const uint64_t sevens = ballot(kind == U32(3u))) {
+				if (sevens == ~0ull && type == PLANE_NORMAL)
+					return decode_plane_runs(lds, L, T, j, cur, keep);
 				return decode_plane_packed<true, 2>(lds, L, T, j, type, cur, hdr, keep);
+			}
 			if (ballot(kind == U32(2u)) != 0)
 				return decode_plane_packed<true, 1>(lds, L, T, j, type, cur, hdr, keep);
 			return decode_plane_packed<true, 0>(lds, L, T, j, type, cur, hdr, keep);

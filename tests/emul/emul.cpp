@@ -103,6 +103,7 @@ static size_t g_last_fused = 0;
 void emul_set_fused(int on) { g_fused = on; }
 size_t emul_group_any_count(void) { return (size_t)codec::emul_group_any_count(); } // groups of any shape encoded so far
 size_t emul_group4_count(void) { return (size_t)codec::emul_group4_count(); } // groups of four blocks encoded plane by plane so far (superblock_codec.h)
+size_t emul_plane_runs_count(void) { return (size_t)codec::emul_plane_runs_count(); } // planes made of run-length coded values decoded by the short form so far (block_codec.h)
 size_t emul_lz_serial_count(void) { return (size_t)codec::emul_lz_serial_count(); } // mini-LZ blocks decoded by the serial decoder so far (block_codec.h)
 size_t emul_last_fused(void) { return g_last_fused; } // superblocks the last frame sent through the fused path
 

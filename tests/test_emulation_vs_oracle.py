@@ -240,6 +240,24 @@ def test_groups_of_blocks_are_taken_where_they_are_meant_to(oracle, emul):
 
 
 
+def test_planes_of_run_length_coded_values_take_the_short_form(oracle, emul):
+    """decode_plane_runs (block_codec.h): planes all of whose rows are run-length coded values -- `steps`, `runs` -- are decoded
+    without the difference machinery, to the same bytes; mixed planes (`burst`, `slopes`) keep the general form."""
+    emul.emul_plane_runs_count.restype = c_size_t
+    for kind, T, expect in (("steps", 4, True), ("runs", 2, True), ("steps", 8, True), ("rand", 4, False)):
+        data = generate(kind, T, 40 * 256, 3)
+        nb = data.nbytes
+        ref = np.zeros(nb * 2 + 4096, dtype=np.uint8)
+        r1 = oracle.so_block_compress(np_ptr(data), T, nb, np_ptr(ref), ref.nbytes)
+        for mis in (0, 5):
+            dec = np.zeros(nb + 64, dtype=np.uint8)
+            before = emul.emul_plane_runs_count()
+            r3 = emul.emul_block_decompress(np_ptr(ref), r1, T, nb, np_ptr(dec), mis)
+            assert r3 == nb and np.array_equal(dec[:nb], data), (kind, T, mis)
+            took = emul.emul_plane_runs_count() - before
+            assert (took >= 40) == expect, (kind, T, took)
+
+
 def test_mini_lz_blocks_take_the_two_phase_decoder(oracle, emul):
     """lz_decode_256 (block_codec.h) gives up on nothing a valid stream holds -- near and far distances, raw groups, literals with
     their top bit set: the serial decoder behind it is for damaged streams (and the other element sizes) only."""
