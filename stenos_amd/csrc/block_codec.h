@@ -1271,17 +1271,16 @@ WV_FN uint32_t decode_plane_packed(Lds lds, const DecLayout& L, uint32_t T, uint
 			extra = at - rowoff;
 			total = extra + (U32(18u) - popc(rmask)); // (in the last row's lanes: the size of all sixteen)
 		}
-		while (todo) {
-			const uint32_t rl = (uint32_t)__builtin_ctzll(todo);
-			todo &= todo - 1;
-			// (the mask and the size stay in vector registers, the same in all lanes: the step's chain does not pass through the
-			// scalar unit behind the one lane read that makes the address)
-			const U32 at(readlane(rowoff + extra, rl));
-			const U32 mk = lds_ld8(win, at) | (lds_ld8(win, at + 1u) << 8);
-			const U32 sz = U32(18u) - popc(mk);
-			rmask = sel(row == U32(rl >> 2), mk, rmask);
-			extra = extra + sel(row > U32(rl >> 2), sz, U32(0u));
-			total = total + sz;
+		if (todo) {
+			// run-length rows among rows of other kinds: in the order of the rows, each one step (lds_rle_walk_row: the lanes from
+			// the row on read its mask, the lanes behind it add its size); `extra` is per lane what the run-length rows in front
+			// of the lane's row take
+			while (todo) {
+				const uint32_t rl = (uint32_t)__builtin_ctzll(todo);
+				todo &= todo - 1;
+				lds_rle_walk_row(win, readlane(rowoff, rl), rl, extra, rmask);
+			}
+			total = extra + sel(isr, U32(18u) - popc(rmask), U32(0u)); // (in the last row's lanes: the bytes of all of them)
 		}
 		rle_total = readlane(total, 63); // (the same in all lanes behind the loop; the last row's behind the fixed walk)
 		rowoff = rowoff + extra;

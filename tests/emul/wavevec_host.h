@@ -341,6 +341,15 @@ WV_FN U32 lds_ld8(Lds m, const U32& a)
 	for (int i = 0; i < WAVE; ++i) r.l[i] = m[a.l[i]];
 	return r;
 }
+WV_FN void lds_rle_walk_row(Lds m, uint32_t base, uint32_t first, U32& e, U32& mask) // (wavevec.h: one run-length row among rows of other kinds)
+{
+	const uint32_t at = base + e.l[first];
+	const uint32_t mk = (uint32_t)m[at] | ((uint32_t)m[at + 1] << 8);
+	for (int i = (int)first; i < WAVE; ++i)
+		mask.l[i] = mk;
+	for (int i = (int)first + 4; i < WAVE; ++i)
+		e.l[i] += 18 - (uint32_t)__builtin_popcount(mk);
+}
 WV_FN void lds_lz_walk32(Lds m, U32& at, U32& flags, uint32_t B) // (wavevec.h: the 32 groups of a mini-LZ block, every match taken for one byte)
 {
 	uint32_t a = at.l[0];
