@@ -1412,6 +1412,41 @@ WV_FN uint32_t decode_plane_runs(Lds lds, const DecLayout& L, uint32_t T, uint32
 	return psize;
 }
 
+// The same for a plane all of whose rows are run-length coded DIFFERENCES (header 6: piecewise linear data).  A row starts with
+// no difference in force (:248-255), so the rows only meet in the running sum: the lane's four differences out of the selector
+// table (entries 16..31: nothing in front of the lane's own literals), summed inside the lane, one prefix sum over the lanes.
+// Same bytes consumed, same result as decode_plane_packed<true, 1>.
+WV_FN uint32_t decode_plane_slopes(Lds lds, const DecLayout& L, uint32_t T, uint32_t j, uint32_t cur, U32* keep)
+{
+#ifdef WV_HOST_EMULATION
+	++emul_plane_runs_count(); // (the two short forms count together)
+#endif
+	const U32 lane = lane_id_plain();
+	Lds win = lds + L.win;
+	const U32 q = lane & 3u;
+	U32 at(cur + 8), rmask(0u);
+	lds_rle_walk16(win, at, rmask);
+	const uint32_t psize = readlane(at + (U32(18u) - popc(rmask)), 63) - cur;
+	const U32 shift = q << 2;
+	const U32 f = (rmask >> shift) & 0xFu;
+	const U32 before = popc(~rmask & ((U32(1u) << shift) - 1u));
+	const U32 from = at + 1u + before;
+	U32 lo, hi;
+	lds_ld64(win, from, lo, hi);
+	const U32 pool_lo = funnel_shr(hi, lo, from << 3), pool_hi = hi >> ((from & 3u) << 3);
+	const U32 selw = lds_ld32(lds, U32(L.lut + 64) + ((f | sel(before == U32(0u), U32(16u), U32(0u))) << 2));
+	const U32 d = perm_bytes_v(pool_hi, pool_lo, selw);
+	const U32 o0 = d & 0xFFu, o1 = o0 + ((d >> 8) & 0xFFu), o2 = o1 + ((d >> 16) & 0xFFu), o3 = o2 + (d >> 24);
+	const U32 carry = wave_incl_scan(o3) - o3; // what the lanes in front add up to (its low byte counts)
+	const U32 outw = perm_bytes(perm_bytes(o3 + carry, o2 + carry, 0x0c0c0400u), perm_bytes(o1 + carry, o0 + carry, 0x0c0c0400u), 0x05040100u);
+	if (keep)
+		*keep = outw;
+	else
+		store_plane_word(lds, L.img, T, j, outw, pred_all(true));
+	WV_MARK("dec_slopes_end");
+	return psize;
+}
+
 // Decode one NORMAL / NORMAL_RLE plane whose bytes start at window offset `cur` (at most `avail`
 // valid bytes).  Writes rows [0, lines) of plane j into the image or, with `keep`, hands the lane's plane word back instead.
 // Returns bytes consumed or DEC_ERROR.
@@ -1444,8 +1479,11 @@ WV_FN uint32_t decode_plane(Lds lds, const DecLayout& L, uint32_t T, uint32_t j,
 					return decode_plane_runs(lds, L, T, j, cur, keep);
 				return decode_plane_packed<true, 2>(lds, L, T, j, type, cur, hdr, keep);
 			}
-			if (ballot(kind == U32(2u)) != 0)
+			if (const uint64_t sixes = ballot(kind == U32(2u))) {
+				if (sixes == ~0ull && type == PLANE_NORMAL)
+					return decode_plane_slopes(lds, L, T, j, cur, keep);
 				return decode_plane_packed<true, 1>(lds, L, T, j, type, cur, hdr, keep);
+			}
 			return decode_plane_packed<true, 0>(lds, L, T, j, type, cur, hdr, keep);
 		}
 		return decode_plane_packed<false, 0>(lds, L, T, j, type, cur, hdr, keep);
